@@ -1,0 +1,291 @@
+/*
+ * lvdhip.h — C ABI of the MI355X (gfx950) denoise-step kernel library.
+ *
+ * The reference (TonyLianLong/LLM-groundedVideoDiffusion) has NO native layer: every
+ * op on its hot path is an ATen call made from Python.  This header therefore declares
+ * the boundary the reference *would* bind if its hot path were native: one entry point
+ * per ATen op-group of SURVEY.md §2.3 (K1..K18).  Each declaration cites the reference
+ * call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain C types only; all tensors are caller-owned device pointers (the library never
+ *     allocates, frees or synchronises); every call is asynchronous on `stream`
+ *     (a hipStream_t passed as void*).
+ *   - activations are "token matrices": row-major [rows, channels] bf16, rows ordered
+ *     (batch, frame, y, x).  `ld*` = row stride in elements.
+ *   - return value: 0 on success, non-zero on error; lvdhip_last_error() gives the text
+ *     (thread-local).
+ *   - bf16 storage is uint16_t; statistics / losses / gradients of the loss are fp32.
+ */
+#ifndef LVDHIP_H
+#define LVDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t lvd_bf16;
+
+const char* lvdhip_last_error(void);
+int lvdhip_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM family:  OUT[M,N] = epilogue( Aload(...)[M,K] · W[N,K]^T )
+ * Replaces: nn.Linear (to_q/k/v/out, proj_in/out, GEGLU/FF, time_emb_proj, PositionNet)
+ *   models/attention_processor.py:382-413, models/attention.py:355-376,
+ *   models/transformer_2d.py:326,363, models/transformer_temporal.py:158,175;
+ * nn.Conv2d 3x3 / 1x1 of ResnetBlock2D, Downsample2D, Upsample2D, conv_in/out
+ *   models/unet_3d_condition.py:729,847, models/unet_3d_blocks.py:330-349 (diffusers resnet);
+ * nn.Conv3d (3,1,1) of TemporalConvLayer  models/unet_3d_blocks.py:195-199;
+ * torch.cat(dim=1) skip connection (two-source A)  models/unet_3d_blocks.py:641,736;
+ * and their input-gradients (dgrad) in torch.autograd.grad  models/pipelines.py:120.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  LVD_A_PLAIN = 0,      /* A[m,k] = X[m, k] (k < C1 from a1, else from a2) */
+  LVD_A_CONV3X3 = 1,    /* implicit im2col, K = 9*Cin, tap-major; stride 1|2, optional nearest x2 upsampled source */
+  LVD_A_TCONV3 = 2,     /* temporal 3-tap, K = 3*Cin, frames at row distance HW */
+  LVD_A_CONV3X3_T2 = 3  /* transposed (dgrad of the stride-2 pad-1 conv): K = 9*Cin */
+};
+enum { LVD_ACT_NONE = 0, LVD_ACT_GEGLU = 1 };
+
+typedef struct {
+  const lvd_bf16* a1;      /* first A source  [rows, lda1] */
+  const lvd_bf16* a2;      /* second A source [rows, lda2] (channel concat) or NULL */
+  const lvd_bf16* w;       /* [N, K] row-major, K contiguous */
+  const float* bias;       /* [N] or NULL */
+  const float* rowbias;    /* [M / rows_per_sample, N] or NULL (temb projection add) */
+  const lvd_bf16* res;     /* [M, ldres] residual or NULL */
+  void* out;               /* [M, ldc] bf16 (or fp32 if out_fp32) */
+  int32_t M, N, K;
+  int32_t lda1, lda2, c1;  /* c1 = channels taken from a1 (per tap); Cin = c1 + c2 */
+  int32_t cin;             /* channels per tap (PLAIN: = K) */
+  int32_t mode;            /* LVD_A_* */
+  int32_t hin, win;        /* conv: input spatial dims (after optional upsample) */
+  int32_t hout, wout;      /* conv: output spatial dims; rows m = (n, oy, ox) */
+  int32_t stride;          /* conv stride 1|2 */
+  int32_t upsample;        /* 1: a1 is stored at (hin/2, win/2) and nearest-upsampled on the fly */
+  int32_t frames, hw;      /* tconv: frames per batch item, rows per frame */
+  int32_t rows_per_sample; /* rowbias granularity */
+  int32_t ldres, ldc;
+  int32_t act;             /* LVD_ACT_* (GEGLU: W rows interleaved hidden/gate in blocks of 32; out has N/2 cols) */
+  int32_t out_fp32;
+  float alpha;             /* out = res + alpha * (acc + bias + rowbias) */
+  int32_t accumulate;      /* 1: out += (bf16 read-modify-write; used for gradient accumulation) */
+} lvd_gemm_params;
+
+int lvdhip_gemm(const lvd_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) over a token matrix.  A "sample" is rows_per_sample consecutive rows:
+ *   2-D GroupNorm  (ResnetBlock2D.norm1/2, Transformer2DModel.norm  models/transformer_2d.py:314):
+ *       rows_per_sample = H*W (statistics per frame)
+ *   5-D GroupNorm  (TransformerTemporalModel.norm models/transformer_temporal.py:148-153,
+ *       TemporalConvLayer norms): rows_per_sample = F*H*W (statistics across frames)
+ * stats: partial per-channel sums -> finalize to per (sample, channel) scale/shift:
+ *   y = silu?( x * scale[s,c] + shift[s,c] )
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const lvd_bf16* x1; const lvd_bf16* x2;   /* channel concat of two sources (x2 may be NULL) */
+  int32_t ld1, ld2, c1, c;                  /* c = total channels */
+  int32_t rows, rows_per_sample, groups;
+  float eps;
+  const float* gamma; const float* beta;    /* [c] */
+  float* partial;      /* workspace: [samples, chunks, c, 2] fp32 */
+  int32_t chunks;
+  float* scale_shift;  /* out: [samples, c, 2] fp32 (scale, shift) */
+  float* mean_rstd;    /* out: [samples, groups, 2] fp32 (kept for backward) */
+} lvd_gn_stats_params;
+int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream);
+
+typedef struct {
+  const lvd_bf16* x1; const lvd_bf16* x2;
+  int32_t ld1, ld2, c1, c;
+  int32_t rows, rows_per_sample;
+  const float* scale_shift;   /* [samples, c, 2] */
+  int32_t silu;
+  lvd_bf16* y; int32_t ldy;
+} lvd_gn_apply_params;
+int lvdhip_groupnorm_apply(const lvd_gn_apply_params* p, void* stream);
+
+/* GroupNorm backward (dgrad): given dy (grad wrt the (SiLU'd) output), x, saved mean/rstd:
+ *   dx = rstd * ( g - mean_g(g) - xhat * mean_g(g * xhat) ),  g = dy * silu'(yhat) * gamma  */
+typedef struct {
+  const lvd_bf16* x1; const lvd_bf16* x2; int32_t ld1, ld2, c1, c;
+  const lvd_bf16* dy; int32_t lddy;
+  int32_t rows, rows_per_sample, groups;
+  const float* gamma; const float* beta;
+  const float* mean_rstd;     /* [samples, groups, 2] */
+  float* partial; int32_t chunks;  /* [samples, chunks, c, 2] */
+  float* gsum;                /* out: [samples, groups, 2] = (mean_g(g), mean_g(g*xhat)) */
+  int32_t silu;
+} lvd_gn_bwd_stats_params;
+int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void* stream);
+
+typedef struct {
+  const lvd_bf16* x1; const lvd_bf16* x2; int32_t ld1, ld2, c1, c;
+  const lvd_bf16* dy; int32_t lddy;
+  int32_t rows, rows_per_sample, groups;
+  const float* gamma; const float* beta;
+  const float* mean_rstd; const float* gsum;
+  int32_t silu;
+  lvd_bf16* dx1; lvd_bf16* dx2; int32_t lddx1, lddx2;  /* grads of the two sources */
+  int32_t accumulate;         /* 1: dx += */
+} lvd_gn_bwd_apply_params;
+int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over channels (BasicTransformerBlock.norm1/2/3, GatedSelfAttentionDense.norm1/2
+ *   models/attention.py:113,140,153,36-37), eps 1e-5, affine.  Saves (mean, rstd) per row.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const lvd_bf16* x; int32_t ldx;
+  int32_t rows, c;
+  const float* gamma; const float* beta; float eps;
+  lvd_bf16* y; int32_t ldy;
+  float* mean_rstd;   /* [rows, 2] or NULL */
+} lvd_ln_params;
+int lvdhip_layernorm(const lvd_ln_params* p, void* stream);
+
+typedef struct {
+  const lvd_bf16* x; int32_t ldx;
+  const lvd_bf16* dy; int32_t lddy;
+  int32_t rows, c;
+  const float* gamma; const float* mean_rstd;
+  lvd_bf16* dx; int32_t lddx;
+  int32_t accumulate;
+} lvd_ln_bwd_params;
+int lvdhip_layernorm_bwd(const lvd_ln_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention, head_dim 64, flash-style (never materialises scores in HBM).
+ * Replaces F.scaled_dot_product_attention  models/attention_processor.py:344-430 and the
+ * baddbmm+softmax+bmm slow path  :222-258,515-536.
+ * One "sample" s = (s_outer, s_inner); query i of sample s lives at token row
+ *     q_os*s_outer + q_is*s_inner + q_step*i        (s_inner in [0, q_ninner))
+ * and key j at kv_os*(s / kv_div) ... see fields.  This single addressing scheme covers
+ *   spatial self-attn   (sample = frame, rows contiguous),
+ *   temporal self-attn  (sample = (batch, pixel), rows HW apart: the (B·F,HW,C)<->(B·HW,F,C)
+ *                        swap of models/transformer_temporal.py:154-156,175-182 is fused
+ *                        into the loads/stores),
+ *   text cross-attn     (K/V rows = 77 text tokens of the batch item),
+ *   GLIGEN gated self-attn (second K/V segment = 30 grounding tokens, models/attention.py:44-57).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const lvd_bf16* q; int32_t ldq;       /* head h at column h*64 */
+  const lvd_bf16* k; int32_t ldk;
+  const lvd_bf16* v; int32_t ldv;
+  const lvd_bf16* k2; const lvd_bf16* v2; int32_t ldk2, ldv2;  /* optional 2nd KV segment */
+  lvd_bf16* o; int32_t ldo;
+  float* lse;                           /* [samples, heads, sq] natural-log LSE or NULL */
+  int32_t samples, heads, sq, skv, skv2;
+  int32_t q_ninner, q_os, q_is, q_step;       /* query row addressing */
+  int32_t kv_ninner, kv_os, kv_is, kv_step;   /* key/value row addressing (segment 1) */
+  int32_t kv2_ninner, kv2_os, kv2_is, kv2_step;
+  float scale;
+} lvd_attn_params;
+int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream);
+
+/* backward: dq (always), dk/dv (if dk != NULL).  delta = rowsum(do*o) is computed inside. */
+typedef struct {
+  lvd_attn_params f;                    /* forward description (o, lse must be valid) */
+  const lvd_bf16* d_o; int32_t lddo;
+  lvd_bf16* dq; int32_t lddq;
+  lvd_bf16* dk; int32_t lddk;           /* segment-1 grads; NULL => skip (cross-attn: text has no grad) */
+  lvd_bf16* dv; int32_t lddv;
+  float* delta;                         /* workspace [samples, heads, sq] */
+} lvd_attn_bwd_params;
+int lvdhip_attention_bwd(const lvd_attn_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cross-attention-energy guidance loss, fused forward+backward.
+ * Replaces AttnProcessor slow path that materialises + saves probs
+ *   (models/attention_processor.py:515-586) and utils/guidance.py:160-574
+ *   (add_ca_loss_per_attn_map_to_loss / compute_ca_lossv3) and the autograd backward of both.
+ * Phase 1: probs of the object tokens only   A[f,h,t,p]   (+ row LSE)
+ * Phase 2: per (frame, head, object, token): top-k energy + centre-of-mass terms,
+ *          loss partials and dA
+ * Phase 3: softmax backward over the 77 keys and dQ = scale * dS * K
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const lvd_bf16* q; int32_t ldq;       /* [frames*P, heads*64] queries of the keyed layer */
+  const lvd_bf16* k; int32_t ldk;       /* [ntext(77), heads*64] text keys */
+  int32_t frames, heads, P, ntext;
+  float scale;
+  const int32_t* tok_ids;               /* [ntok] text-token index of every (object, token) pair */
+  int32_t ntok;
+  float* probs;                         /* out [frames, heads, ntok, P] fp32 */
+  float* lse;                           /* out [frames, heads, P] */
+} lvd_ca_probs_params;
+int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream);
+
+typedef struct {
+  const float* probs;                   /* [frames, heads, ntok, P] */
+  float* dprobs;                        /* out, same shape (zero where no gradient) */
+  int32_t frames, heads, P, ntok, H, W; /* P = H*W */
+  const int32_t* tok_obj;               /* [ntok] object index of each token column */
+  const int32_t* boxes;                 /* [nobj, frames, 4] integer (x_min,y_min,x_max,y_max) at (H,W) */
+  const float* tok_weight;              /* [ntok] = 1/|T_o| */
+  int32_t nobj;
+  float fg_top_p, bg_top_p, fg_weight, bg_weight, com_loss_scale;
+  float grad_scale;                     /* loss_scale / (nobj * nkeys) */
+  float* loss_partial;                  /* out [frames*heads*ntok] un-scaled partial sums (+ com in slot) */
+  float* com_ws;                        /* workspace [frames, heads, ntok, 4] (sum, com_y, com_x, pad) */
+} lvd_ca_select_params;
+int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream);
+
+typedef struct {
+  const lvd_bf16* q; int32_t ldq;
+  const lvd_bf16* k; int32_t ldk;
+  int32_t frames, heads, P, ntext;
+  float scale;
+  const int32_t* tok_ids; int32_t ntok;
+  const float* probs; const float* dprobs; const float* lse;
+  lvd_bf16* dq; int32_t lddq;           /* out [frames*P, heads*64] */
+} lvd_ca_dq_params;
+int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / layout kernels.
+ * ------------------------------------------------------------------------------------------ */
+/* (B,4,F,h,w) fp32 latents -> token matrix [B*F*h*w, cpad] bf16 (channels zero-padded);
+ * replaces the permute+reshape of models/unet_3d_condition.py:726-728 */
+int lvdhip_latents_to_tokens(const float* latents, lvd_bf16* tokens, int32_t B, int32_t C, int32_t F,
+                             int32_t HW, int32_t cpad, float scale, void* stream);
+/* token matrix fp32 [B*F*HW, ld] -> (B,C,F,h,w) fp32; models/unet_3d_condition.py:850-854 */
+int lvdhip_tokens_to_latents(const float* tokens, int32_t ld, float* latents, int32_t B, int32_t C,
+                             int32_t F, int32_t HW, void* stream);
+/* dgrad of latents_to_tokens: token grads bf16 [rows, ld] -> (B,C,F,h,w) fp32 */
+int lvdhip_tokens_grad_to_latents(const lvd_bf16* tokens, int32_t ld, float* latents, int32_t B,
+                                  int32_t C, int32_t F, int32_t HW, float scale, void* stream);
+/* y = a + b (bf16) ; gradient accumulation and residual adds */
+int lvdhip_add(const lvd_bf16* a, int32_t lda, const lvd_bf16* b, int32_t ldb, lvd_bf16* y, int32_t ldy,
+               int32_t rows, int32_t c, void* stream);
+/* GEGLU pieces for the recorded (guidance) pass: pre = [hidden | gate] interleaved as the GEMM emits them */
+int lvdhip_geglu_fwd(const lvd_bf16* pre, int32_t ldp, lvd_bf16* y, int32_t ldy, int32_t rows, int32_t n_out,
+                     void* stream);
+int lvdhip_geglu_bwd(const lvd_bf16* pre, int32_t ldp, const lvd_bf16* dy, int32_t lddy, lvd_bf16* dpre,
+                     int32_t lddp, int32_t rows, int32_t n_out, void* stream);
+/* SiLU backward is folded into groupnorm_bwd; nearest-upsample backward = 2x2 sum */
+int lvdhip_upsample2x_bwd(const lvd_bf16* dy, lvd_bf16* dx, int32_t n, int32_t h, int32_t w, int32_t c,
+                          int32_t accumulate, void* stream);
+/* sinusoidal timestep embedding (diffusers Timesteps(flip_sin_to_cos=True, shift 0)) -> bf16 [n, dim] */
+int lvdhip_timestep_embedding(const float* t, lvd_bf16* out, int32_t n, int32_t dim, void* stream);
+/* silu on a small bf16 matrix (temb) */
+int lvdhip_silu(const lvd_bf16* x, lvd_bf16* y, int64_t n, void* stream);
+/* CFG combine + DPM-Solver++(2M) update (models/controllable_pipeline_text_to_video_synth.py:926-950):
+ *   eps = eu + s*(ec-eu);  x0 = (x - sigma_t*eps)/alpha_t;
+ *   x' = c_x*x + c_0*x0 + c_1*x0_prev ; x0_prev <- x0       (all fp32, (B,4,F,h,w) layout) */
+int lvdhip_cfg_dpm_step(const float* eps_uncond, const float* eps_cond, float guidance_scale, float* x,
+                        float* x0_prev, float alpha_t, float sigma_t, float c_x, float c_0, float c_1,
+                        int64_t n, void* stream);
+/* latents -= scale * grad   (models/pipelines.py:124-132) */
+int lvdhip_axpy(float* x, const float* g, float scale, int64_t n, void* stream);
+/* deterministic sum of n floats -> out[0] (times scale) */
+int lvdhip_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVDHIP_H */

@@ -1,0 +1,181 @@
+// attention.hip — flash-style attention forward for head_dim 64 on gfx950 (MFMA 32x32x16 bf16).
+//
+// One wave owns a 32-query tile of one (sample, head) and streams the keys in tiles of 32:
+//   S^T[key][query] = K · Q^T          A operand = K rows (16-byte global loads, d contiguous)
+//                                       B operand = Q rows (resident in registers)
+//   => every lane holds 16 of the 32 scores of ITS query (lane&31): the online softmax is
+//      lane-local plus one cross-half shuffle, and P never leaves registers.
+//   O^T[d][query]  = V^T · P^T          A operand = V^T fragment (V tile transposed through LDS),
+//                                       B operand = P registers as they are
+//   The contraction (key) index of an MFMA operand can be permuted freely as long as A and B agree:
+//   the accumulator layout gives lane (query, hi) the keys {4hi..4hi+3, 4hi+8..4hi+11} (+16·step),
+//   so the V^T fragment is read in exactly that key order and no permlane/LDS round trip of P is needed.
+// The row addressing (base + step·i per sample) lets the same kernel serve spatial self-attention,
+// text cross-attention (77 keys), temporal attention (rows HW apart — the reference's
+// (B·F,HW,C)<->(B·HW,F,C) permutes, models/transformer_temporal.py:154-156,175-182, are fused away)
+// and the GLIGEN fuser (second key/value segment of 30 grounding tokens, models/attention.py:51-57).
+#include "common.h"
+
+namespace {
+
+LVD_DEV long base_row(int s, int ninner, int os, int is) {
+  int so = s / ninner;
+  int si = s - so * ninner;
+  return (long)so * os + (long)si * is;
+}
+
+constexpr int VT_PITCH = 18;  // dwords per d-row of the transposed V tile (16 key pairs + 2 pad)
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
+  __shared__ uint32_t vt[64 * VT_PITCH];
+
+  const int lane = threadIdx.x;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.sq + 31) >> 5;
+  const int s = blockIdx.x / nqt, qt = blockIdx.x - s * nqt, h = blockIdx.y;
+
+  const long qbase = base_row(s, p.q_ninner, p.q_os, p.q_is);
+  const long kvbase = base_row(s, p.kv_ninner, p.kv_os, p.kv_is);
+  const long kv2base = p.skv2 > 0 ? base_row(s, p.kv2_ninner, p.kv2_os, p.kv2_is) : 0;
+  const int skv_tot = p.skv + p.skv2;
+
+  const int qi = qt * 32 + l31;
+  const int qic = min(qi, p.sq - 1);
+  const long qrow = qbase + (long)qic * p.q_step;
+
+  bf16x8 qf[4];
+  {
+    const lvd_bf16* qp = p.q + qrow * p.ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
+  }
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+  float m = -1e30f, lsum = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;
+
+  const int vj = lane & 15, vdc = lane >> 4;
+
+  for (int kt = 0; kt * 32 < skv_tot; ++kt) {
+    // ---- S^T = K · Q^T
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+    {
+      int kk = min(kt * 32 + l31, skv_tot - 1);
+      const lvd_bf16* kp = (kk < p.skv) ? p.k + (kvbase + (long)kk * p.kv_step) * p.ldk
+                                        : p.k2 + (kv2base + (long)(kk - p.skv) * p.kv2_step) * p.ldk2;
+      kp += h * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 kf = as_bf16x8(ldg16(kp + ks * 16));
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+      }
+    }
+    // ---- V tile -> LDS, transposed: vt[d][key pair]
+    {
+      int k0 = min(kt * 32 + 2 * vj, skv_tot - 1);
+      int k1 = min(kt * 32 + 2 * vj + 1, skv_tot - 1);
+      const lvd_bf16* v0 = (k0 < p.skv) ? p.v + (kvbase + (long)k0 * p.kv_step) * p.ldv
+                                        : p.v2 + (kv2base + (long)(k0 - p.skv) * p.kv2_step) * p.ldv2;
+      const lvd_bf16* v1 = (k1 < p.skv) ? p.v + (kvbase + (long)k1 * p.kv_step) * p.ldv
+                                        : p.v2 + (kv2base + (long)(k1 - p.skv) * p.kv2_step) * p.ldv2;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        int d0 = vdc * 8 + 32 * half;
+        uint4 a = ldg16(v0 + h * 64 + d0);
+        uint4 b = ldg16(v1 + h * 64 + d0);
+        uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vt[(d0 + 2 * e) * VT_PITCH + vj] = (aw[e] & 0xffffu) | (bw[e] << 16);
+          vt[(d0 + 2 * e + 1) * VT_PITCH + vj] = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- online softmax (lane-local over this lane's 16 keys + partner half)
+    float pv[16];
+    float tmax = -1e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      float v = (kidx < skv_tot) ? st[e] * sc : -1e30f;
+      pv[e] = v;
+      tmax = fmaxf(tmax, v);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    float mn = fmaxf(m, tmax);
+    float alpha = exp2f(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { pv[e] = exp2f(pv[e] - mn); rs += pv[e]; }
+    lsum = lsum * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+
+    // ---- O^T += V^T · P^T
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      uint4 pw;
+      pw.x = pack2bf(pv[ks2 * 8 + 0], pv[ks2 * 8 + 1]);
+      pw.y = pack2bf(pv[ks2 * 8 + 2], pv[ks2 * 8 + 3]);
+      pw.z = pack2bf(pv[ks2 * 8 + 4], pv[ks2 * 8 + 5]);
+      pw.w = pack2bf(pv[ks2 * 8 + 6], pv[ks2 * 8 + 7]);
+      bf16x8 pf = as_bf16x8(pw);
+      int kd = ks2 * 8 + 2 * hi;  // dword offset of keys (16·ks2 + 4·hi)
+      {
+        const uint32_t* r = vt + l31 * VT_PITCH + kd;
+        uint2 lo = *reinterpret_cast<const uint2*>(r);
+        uint2 hi2 = *reinterpret_cast<const uint2*>(r + 4);
+        bf16x8 vf = as_bf16x8(make_uint4(lo.x, lo.y, hi2.x, hi2.y));
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
+      }
+      {
+        const uint32_t* r = vt + (32 + l31) * VT_PITCH + kd;
+        uint2 lo = *reinterpret_cast<const uint2*>(r);
+        uint2 hi2 = *reinterpret_cast<const uint2*>(r + 4);
+        bf16x8 vf = as_bf16x8(make_uint4(lo.x, lo.y, hi2.x, hi2.y));
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  float inv = 1.f / ltot;
+  if (qi < p.sq) {
+    const long orow = qbase + (long)qi * p.q_step;
+    lvd_bf16* op = p.o + orow * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      uint2 w0, w1;
+      w0.x = pack2bf(o0[rq * 4 + 0] * inv, o0[rq * 4 + 1] * inv);
+      w0.y = pack2bf(o0[rq * 4 + 2] * inv, o0[rq * 4 + 3] * inv);
+      w1.x = pack2bf(o1[rq * 4 + 0] * inv, o1[rq * 4 + 1] * inv);
+      w1.y = pack2bf(o1[rq * 4 + 2] * inv, o1[rq * 4 + 3] * inv);
+      stg8(op + 8 * rq, w0);
+      stg8(op + 32 + 8 * rq, w1);
+    }
+    if (p.lse && hi == 0) p.lse[((long)s * p.heads + h) * p.sq + qi] = (m + log2f(ltot)) * 0.6931471805599453f;
+  }
+}
+
+}  // namespace
+
+extern "C" int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream) {
+  LVD_CHECK(p && p->q && p->k && p->v && p->o, "attention_fwd: null pointer");
+  LVD_CHECK(p->sq > 0 && p->skv > 0 && p->samples > 0 && p->heads > 0, "attention_fwd: bad sizes");
+  LVD_CHECK(p->skv2 == 0 || (p->k2 && p->v2), "attention_fwd: second KV segment pointers missing");
+  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 4 == 0, "attention_fwd: leading dims must be multiples of 8");
+  LVD_CHECK(p->heads <= 65535, "attention_fwd: too many heads");
+  LVD_CHECK(p->q_ninner > 0 && p->kv_ninner > 0, "attention_fwd: ninner must be > 0");
+  dim3 grid(((p->sq + 31) / 32) * p->samples, p->heads);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,72 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lvdhip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LVD_DEV __device__ __forceinline__
+
+LVD_DEV float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+LVD_DEV uint16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+LVD_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+LVD_DEV float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+LVD_DEV float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+LVD_DEV uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+LVD_DEV uint2 ldg8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
+LVD_DEV void stg16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+LVD_DEV void stg8(void* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
+
+LVD_DEV bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+LVD_DEV float silu_f(float x) { return x / (1.f + __expf(-x)); }
+LVD_DEV float silu_grad_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+LVD_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+LVD_DEV float gelu_erf_grad_f(float x) {
+  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+LVD_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+LVD_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host-side error plumbing (capi.cpp)
+void lvd_set_error(const char* fmt, ...);
+#define LVD_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      lvd_set_error(__VA_ARGS__);       \
+      return 1;                         \
+    }                                   \
+  } while (0)
+#define LVD_LAUNCH_CHECK()                                             \
+  do {                                                                 \
+    hipError_t e_ = hipGetLastError();                                 \
+    if (e_ != hipSuccess) {                                            \
+      lvd_set_error("launch failed: %s", hipGetErrorString(e_));       \
+      return 2;                                                        \
+    }                                                                  \
+  } while (0)

@@ -1,0 +1,286 @@
+// gemm.hip — bf16 MFMA GEMM family for gfx950:  OUT[M,N] = epi( Aload[M,K] · W[N,K]^T ).
+//
+// One kernel template covers every dense contraction of the denoise step (SURVEY §2.3 K3-K8,
+// K11-K14, K16): the A operand is generated on the fly by a loader —
+//   PLAIN      token matrix (optionally the channel-concat of two matrices: the skip "torch.cat")
+//   CONV3X3    implicit im2col of a 3x3 pad-1 conv (stride 1|2, optional nearest-x2 source)
+//   TCONV3     3-tap temporal conv: the taps are the same token matrix shifted by ±HW rows
+//   CONV3X3_T2 transposed stride-2 conv (input-gradient of Downsample2D)
+// so no im2col buffer, no concat buffer and no (B·F,C,H,W)<->(B,C,F,H,W) permute ever touch HBM.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2, each 64x64 = 2x2 MFMA 32x32x16 tiles),
+// register-staged global->LDS double buffer (one barrier per K-tile), XOR-swizzled LDS rows so the
+// ds_read_b128 fragment reads are conflict-free, XCD-aware block->tile map (consecutive tiles of an
+// XCD share the A row-panel in that XCD's L2).  Epilogue goes through LDS so that bias / temb row
+// bias / GEGLU / gate / residual are applied on 8-16 byte row-contiguous vectors.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct ARow {
+  long off1, off2;  // PLAIN: row offsets; CONV: image base row (off1) ; TCONV: row index m (off1)
+  int oy, ox;       // CONV: output pixel; TCONV: oy = frame index
+  bool valid;
+};
+
+template <int MODE>
+LVD_DEV uint4 load_a(const lvd_gemm_params& p, const ARow& r, int k0) {
+  uint4 z = make_uint4(0, 0, 0, 0);
+  if (!r.valid || k0 >= p.K) return z;
+  if (MODE == LVD_A_PLAIN) {
+    if (k0 < p.c1) return ldg16(p.a1 + r.off1 + k0);
+    return ldg16(p.a2 + r.off2 + (k0 - p.c1));
+  } else if (MODE == LVD_A_CONV3X3) {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ky = tap / 3, kx = tap - 3 * ky;
+    int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
+    if (iy < 0 || iy >= p.hin || ix < 0 || ix >= p.win) return z;
+    int ws = p.win;
+    if (p.upsample) { iy >>= 1; ix >>= 1; ws >>= 1; }
+    long row = r.off1 + (long)iy * ws + ix;
+    if (c < p.c1) return ldg16(p.a1 + row * p.lda1 + c);
+    return ldg16(p.a2 + row * p.lda2 + (c - p.c1));
+  } else if (MODE == LVD_A_CONV3X3_T2) {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ky = tap / 3, kx = tap - 3 * ky;
+    int ty = r.oy + 1 - ky, tx = r.ox + 1 - kx;
+    if (ty < 0 || tx < 0 || (ty & 1) || (tx & 1)) return z;
+    ty >>= 1; tx >>= 1;
+    if (ty >= p.hin || tx >= p.win) return z;
+    long row = r.off1 + (long)ty * p.win + tx;
+    return ldg16(p.a1 + row * p.lda1 + c);
+  } else {  // TCONV3
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ff = r.oy + tap - 1;
+    if (ff < 0 || ff >= p.frames) return z;
+    long row = r.off1 + (long)(tap - 1) * p.hw;
+    if (c < p.c1) return ldg16(p.a1 + row * p.lda1 + c);
+    return ldg16(p.a2 + row * p.lda2 + (c - p.c1));
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
+  __shared__ uint4 lds[2 * (BM + BN) * 8];  // 64 KiB: 2 buffers x (A 128 rows + B 128 rows) x 8 x 16 B
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-aware bijective remap: blocks b, b+8, b+16.. (same XCD) get consecutive tile ids
+  const int nb = gridDim.x;
+  int id;
+  {
+    int bid = blockIdx.x;
+    int q = nb >> 3, r = nb & 7;
+    int xcd = bid & 7, idx = bid >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+
+  const int vc = tid & 7;   // 16-byte chunk (8 bf16) within the 64-wide K tile
+  const int r0 = tid >> 3;  // 0..31
+
+  ARow ar[4];
+  long woff[4];
+  bool wvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = tm * BM + r0 + 32 * i;
+    ar[i].valid = m < p.M;
+    ar[i].off1 = 0; ar[i].off2 = 0; ar[i].oy = 0; ar[i].ox = 0;
+    if (MODE == LVD_A_PLAIN) {
+      ar[i].off1 = (long)m * p.lda1;
+      ar[i].off2 = (long)m * p.lda2;
+    } else if (MODE == LVD_A_CONV3X3 || MODE == LVD_A_CONV3X3_T2) {
+      int plane = p.hout * p.wout;
+      int nimg = m / plane;
+      int rem = m - nimg * plane;
+      ar[i].oy = rem / p.wout;
+      ar[i].ox = rem - ar[i].oy * p.wout;
+      int hs = p.hin, ws = p.win;
+      if (MODE == LVD_A_CONV3X3 && p.upsample) { hs >>= 1; ws >>= 1; }
+      ar[i].off1 = (long)nimg * hs * ws;
+    } else {
+      ar[i].off1 = m;
+      ar[i].oy = (m / p.hw) % p.frames;
+    }
+    int n = tn * BN + r0 + 32 * i;
+    wvalid[i] = n < p.N;
+    woff[i] = (long)n * p.K;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  uint4 ra[4], rb[4];
+
+  auto load_tile = [&](int kt) {
+    int k0 = kt * BK + vc * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = load_a<MODE>(p, ar[i], k0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rb[i] = (wvalid[i] && k0 < p.K) ? ldg16(p.w + woff[i] + k0) : make_uint4(0, 0, 0, 0);
+  };
+  auto store_tile = [&](int buf) {
+    uint4* A = lds + buf * 2048;
+    uint4* B = A + 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = r0 + 32 * i;
+      int sw = vc ^ ((row >> 1) & 7);
+      A[row * 8 + sw] = ra[i];
+      B[row * 8 + sw] = rb[i];
+    }
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const uint4* A = lds + cur * 2048;
+    const uint4* B = A + 1024;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int row = wm * 64 + i * 32 + l31;
+        af[i] = as_bf16x8(A[row * 8 + ((ks * 2 + hi) ^ ((row >> 1) & 7))]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = wn * 64 + j * 32 + l31;
+        bfr[j] = as_bf16x8(B[row * 8 + ((ks * 2 + hi) ^ ((row >> 1) & 7))]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: stage the wave's 64x64 fp32 tile in LDS, then row-contiguous vector math ----
+  float* S = reinterpret_cast<float*>(lds) + wave * 4096;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int rowl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        S[rowl * 64 + j * 32 + l31] = acc[i][j][e];
+      }
+  __syncthreads();
+
+  const int mbase = tm * BM + wm * 64;
+  const int nbase = tn * BN + wn * 64;
+
+  if (p.act == LVD_ACT_GEGLU) {
+    const int ldc = p.ldc;
+    lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      int idx = it * 64 + lane;
+      int row = idx >> 3, cq = idx & 7;
+      int m = mbase + row;
+      int n = nbase + cq * 4;  // hidden column in the interleaved W'; gate = n + 32
+      if (m >= p.M || n + 32 >= p.N) continue;
+      f32x4 h = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
+      f32x4 g = *reinterpret_cast<const f32x4*>(&S[row * 64 + 32 + cq * 4]);
+      if (p.bias) {
+        f32x4 bh = *reinterpret_cast<const f32x4*>(p.bias + n);
+        f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+        h += bh; g += bg;
+      }
+      int oc = (nbase >> 1) + cq * 4;
+      uint2 o;
+      o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
+      o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+      stg8(out + (long)m * ldc + oc, o);
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    int idx = it * 64 + lane;
+    int row = idx >> 4, cq = idx & 15;
+    int m = mbase + row;
+    int n = nbase + cq * 4;
+    if (m >= p.M || n >= p.N) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
+    v *= p.alpha;
+    if (p.res) {
+      uint2 r = ldg8(p.res + (long)m * p.ldres + n);
+      v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+    }
+    if (p.out_fp32) {
+      float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    } else {
+      lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+      if (p.accumulate) {
+        uint2 r = ldg8(o);
+        v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+      }
+      uint2 w;
+      w.x = pack2bf(v[0], v[1]);
+      w.y = pack2bf(v[2], v[3]);
+      stg8(o, w);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
+  LVD_CHECK(p && p->a1 && p->w && p->out, "gemm: null pointer");
+  LVD_CHECK(p->M > 0 && p->N > 0 && p->K > 0, "gemm: bad shape M=%d N=%d K=%d", p->M, p->N, p->K);
+  LVD_CHECK(p->K % 8 == 0 && p->N % 4 == 0, "gemm: K%%8 / N%%4 violated (K=%d N=%d)", p->K, p->N);
+  LVD_CHECK(p->cin % 8 == 0 && p->c1 % 8 == 0, "gemm: cin/c1 must be multiples of 8 (cin=%d c1=%d)", p->cin, p->c1);
+  LVD_CHECK(p->lda1 % 8 == 0 && (p->a2 == nullptr || p->lda2 % 8 == 0), "gemm: lda must be a multiple of 8");
+  LVD_CHECK(p->a2 != nullptr || p->c1 >= p->cin, "gemm: c1 < cin needs a second source");
+  if (p->act == LVD_ACT_GEGLU) LVD_CHECK(p->N % 64 == 0 && !p->out_fp32 && !p->res, "gemm: GEGLU needs N%%64==0, bf16 out, no residual");
+  if (p->rowbias) LVD_CHECK(p->rows_per_sample > 0, "gemm: rowbias needs rows_per_sample");
+  if (p->mode == LVD_A_TCONV3) LVD_CHECK(p->frames > 0 && p->hw > 0 && p->K == 3 * p->cin, "gemm: bad tconv dims");
+  if (p->mode == LVD_A_CONV3X3 || p->mode == LVD_A_CONV3X3_T2)
+    LVD_CHECK(p->K == 9 * p->cin && p->hout > 0 && p->wout > 0 && p->hin > 0 && p->win > 0 && p->M % (p->hout * p->wout) == 0,
+              "gemm: bad conv dims");
+  int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
+  dim3 grid(tiles), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (p->mode) {
+    case LVD_A_PLAIN: hipLaunchKernelGGL(gemm_kernel<LVD_A_PLAIN>, grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL(gemm_kernel<LVD_A_CONV3X3>, grid, block, 0, s, *p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL(gemm_kernel<LVD_A_TCONV3>, grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL(gemm_kernel<LVD_A_CONV3X3_T2>, grid, block, 0, s, *p); break;
+    default: LVD_CHECK(false, "gemm: unknown mode %d", p->mode);
+  }
+  LVD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,388 @@
+// norm.hip — GroupNorm(+SiLU) and LayerNorm, forward and input-gradient, on token matrices.
+//
+// HBM-bound kernels (roofline: bytes moved / 8 TB/s).  GroupNorm over a channels-last token
+// matrix: a "sample" is rows_per_sample consecutive rows (H*W rows for the 2-D norms of
+// ResnetBlock2D / Transformer2DModel, F*H*W rows for the 5-D norms of TemporalConvLayer /
+// TransformerTemporalModel — the (B·F,C,H,W)->(B,C,F,H,W) permute of the reference,
+// models/transformer_temporal.py:148-153, is just a different rows_per_sample here).
+// Statistics are two-stage and deterministic: per-channel partial sums per row-chunk
+// (coalesced 8-byte loads, each thread owns 4 channels), then a finalize that folds chunks and the
+// channels of a group and emits per-(sample,channel) scale/shift so the apply pass is one FMA.
+#include "common.h"
+
+namespace {
+
+LVD_DEV void load4(const lvd_bf16* x1, const lvd_bf16* x2, int ld1, int ld2, int c1, long row, int c, float v[4]) {
+  uint2 r = (c < c1) ? ldg8(x1 + row * ld1 + c) : ldg8(x2 + row * ld2 + (c - c1));
+  v[0] = bflo(r.x); v[1] = bfhi(r.x); v[2] = bflo(r.y); v[3] = bfhi(r.y);
+}
+
+// ------------------------------------------------------------------ GroupNorm forward stats
+// grid (chunks, samples); block = VC*RL threads (VC = c/4 channel-quads, RL row lanes)
+__global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
+  extern __shared__ float red[];  // [RL][VC][8]
+  const int t = threadIdx.x;
+  const int vcid = t % VC, rl = t / VC;
+  const int chunk = blockIdx.x, s = blockIdx.y;
+  const int rps = p.rows_per_sample;
+  const int rpc = (rps + p.chunks - 1) / p.chunks;
+  const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
+  const int c = vcid * 4;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    for (int r = rbeg + rl; r < rend; r += RL) {
+      float v[4];
+      load4(p.x1, p.x2, p.ld1, p.ld2, p.c1, (long)s * rps + r, c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[(rl * VC + vcid) * 8 + e] = s1[e]; red[(rl * VC + vcid) * 8 + 4 + e] = s2[e]; }
+  }
+  __syncthreads();
+  if (rl == 0) {
+    for (int q = 1; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += red[(q * VC + vcid) * 8 + e]; s2[e] += red[(q * VC + vcid) * 8 + 4 + e]; }
+    float* out = p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
+  }
+}
+
+// grid samples*groups, block 64
+__global__ void gn_finalize_kernel(const lvd_gn_stats_params p) {
+  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
+  const int cpg = p.c / p.groups;
+  const int lane = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int i = lane; i < p.chunks * cpg; i += 64) {
+    int ch = i / cpg, cc = i % cpg;
+    const float* q = p.partial + (((long)s * p.chunks + ch) * p.c + g * cpg + cc) * 2;
+    a += q[0]; b += q[1];
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  float cnt = (float)cpg * (float)p.rows_per_sample;
+  float mean = a / cnt;
+  float var = fmaxf(b / cnt - mean * mean, 0.f);
+  float rstd = rsqrtf(var + p.eps);
+  if (lane == 0 && p.mean_rstd) {
+    p.mean_rstd[((long)s * p.groups + g) * 2] = mean;
+    p.mean_rstd[((long)s * p.groups + g) * 2 + 1] = rstd;
+  }
+  for (int cc = lane; cc < cpg; cc += 64) {
+    int c = g * cpg + cc;
+    float ga = p.gamma[c], be = p.beta[c];
+    p.scale_shift[((long)s * p.c + c) * 2] = rstd * ga;
+    p.scale_shift[((long)s * p.c + c) * 2 + 1] = be - mean * rstd * ga;
+  }
+}
+
+// ------------------------------------------------------------------ GroupNorm apply (+SiLU)
+__global__ void gn_apply_kernel(const lvd_gn_apply_params p) {
+  const int vpr = p.c >> 3;  // 8-channel vectors per row
+  const long total = (long)p.rows * vpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / vpr;
+    int c = (int)(i - row * vpr) * 8;
+    int s = (int)(row / p.rows_per_sample);
+    uint4 r = (c < p.c1) ? ldg16(p.x1 + row * p.ld1 + c) : ldg16(p.x2 + row * p.ld2 + (c - p.c1));
+    const float* ss = p.scale_shift + ((long)s * p.c + c) * 2;
+    f32x4 q0 = *reinterpret_cast<const f32x4*>(ss);
+    f32x4 q1 = *reinterpret_cast<const f32x4*>(ss + 4);
+    f32x4 q2 = *reinterpret_cast<const f32x4*>(ss + 8);
+    f32x4 q3 = *reinterpret_cast<const f32x4*>(ss + 12);
+    float y[8];
+    y[0] = bflo(r.x) * q0[0] + q0[1]; y[1] = bfhi(r.x) * q0[2] + q0[3];
+    y[2] = bflo(r.y) * q1[0] + q1[1]; y[3] = bfhi(r.y) * q1[2] + q1[3];
+    y[4] = bflo(r.z) * q2[0] + q2[1]; y[5] = bfhi(r.z) * q2[2] + q2[3];
+    y[6] = bflo(r.w) * q3[0] + q3[1]; y[7] = bfhi(r.w) * q3[2] + q3[3];
+    if (p.silu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+    }
+    uint4 o;
+    o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]); o.z = pack2bf(y[4], y[5]); o.w = pack2bf(y[6], y[7]);
+    stg16(p.y + row * p.ldy + c, o);
+  }
+}
+
+// ------------------------------------------------------------------ GroupNorm backward
+// per-channel partials of (g, g*xhat), g = dy * silu'(yhat) * gamma
+__global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, int RL) {
+  extern __shared__ float red[];
+  const int t = threadIdx.x;
+  const int vcid = t % VC, rl = t / VC;
+  const int chunk = blockIdx.x, s = blockIdx.y;
+  const int rps = p.rows_per_sample;
+  const int rpc = (rps + p.chunks - 1) / p.chunks;
+  const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
+  const int c = vcid * 4;
+  const int cpg = p.c / p.groups;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    float mean[4], rstd[4], ga[4], be[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int g = (c + e) / cpg;
+      mean[e] = p.mean_rstd[((long)s * p.groups + g) * 2];
+      rstd[e] = p.mean_rstd[((long)s * p.groups + g) * 2 + 1];
+      ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e];
+    }
+    for (int r = rbeg + rl; r < rend; r += RL) {
+      long row = (long)s * rps + r;
+      float v[4];
+      load4(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
+      uint2 d = ldg8(p.dy + row * p.lddy + c);
+      float dy[4] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh = (v[e] - mean[e]) * rstd[e];
+        float g = dy[e];
+        if (p.silu) g *= silu_grad_f(xh * ga[e] + be[e]);
+        g *= ga[e];
+        s1[e] += g; s2[e] += g * xh;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[(rl * VC + vcid) * 8 + e] = s1[e]; red[(rl * VC + vcid) * 8 + 4 + e] = s2[e]; }
+  }
+  __syncthreads();
+  if (rl == 0) {
+    for (int q = 1; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += red[(q * VC + vcid) * 8 + e]; s2[e] += red[(q * VC + vcid) * 8 + 4 + e]; }
+    float* out = p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
+  }
+}
+
+__global__ void gn_bwd_finalize_kernel(const lvd_gn_bwd_stats_params p) {
+  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
+  const int cpg = p.c / p.groups;
+  const int lane = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int i = lane; i < p.chunks * cpg; i += 64) {
+    int ch = i / cpg, cc = i % cpg;
+    const float* q = p.partial + (((long)s * p.chunks + ch) * p.c + g * cpg + cc) * 2;
+    a += q[0]; b += q[1];
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  float cnt = (float)cpg * (float)p.rows_per_sample;
+  if (lane == 0) {
+    p.gsum[((long)s * p.groups + g) * 2] = a / cnt;
+    p.gsum[((long)s * p.groups + g) * 2 + 1] = b / cnt;
+  }
+}
+
+__global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p) {
+  const int vpr = p.c >> 2;  // 4-channel vectors
+  const int cpg = p.c / p.groups;
+  const long total = (long)p.rows * vpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / vpr;
+    int c = (int)(i - row * vpr) * 4;
+    int s = (int)(row / p.rows_per_sample);
+    float v[4];
+    load4(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
+    uint2 d = ldg8(p.dy + row * p.lddy + c);
+    float dy[4] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y)};
+    float dx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int g = (c + e) / cpg;
+      float mean = p.mean_rstd[((long)s * p.groups + g) * 2];
+      float rstd = p.mean_rstd[((long)s * p.groups + g) * 2 + 1];
+      float m1 = p.gsum[((long)s * p.groups + g) * 2];
+      float m2 = p.gsum[((long)s * p.groups + g) * 2 + 1];
+      float ga = p.gamma[c + e], be = p.beta[c + e];
+      float xh = (v[e] - mean) * rstd;
+      float gg = dy[e];
+      if (p.silu) gg *= silu_grad_f(xh * ga + be);
+      gg *= ga;
+      dx[e] = rstd * (gg - m1 - xh * m2);
+    }
+    lvd_bf16* o = (c < p.c1) ? (p.dx1 + row * p.lddx1 + c) : (p.dx2 + row * p.lddx2 + (c - p.c1));
+    if (p.accumulate) {
+      uint2 r = ldg8(o);
+      dx[0] += bflo(r.x); dx[1] += bfhi(r.x); dx[2] += bflo(r.y); dx[3] += bfhi(r.y);
+    }
+    uint2 w;
+    w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]);
+    stg8(o, w);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm (one wave per row)
+constexpr int LN_MAXV = 4;  // 8-channel vectors per lane -> c <= 2048
+
+__global__ void ln_fwd_kernel(const lvd_ln_params p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int nv = p.c >> 3;
+  float x[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + 64 * j;
+    if (v < nv) {
+      uint4 r = ldg16(p.x + row * p.ldx + v * 8);
+      x[j][0] = bflo(r.x); x[j][1] = bfhi(r.x); x[j][2] = bflo(r.y); x[j][3] = bfhi(r.y);
+      x[j][4] = bflo(r.z); x[j][5] = bfhi(r.z); x[j][6] = bflo(r.w); x[j][7] = bfhi(r.w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[j][e];
+    }
+  }
+  float mean = wave_sum(s) / (float)p.c;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + 64 * j;
+    if (v < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float d = x[j][e] - mean; q += d * d; }
+    }
+  }
+  float rstd = rsqrtf(wave_sum(q) / (float)p.c + p.eps);
+  if (lane == 0 && p.mean_rstd) { p.mean_rstd[row * 2] = mean; p.mean_rstd[row * 2 + 1] = rstd; }
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + 64 * j;
+    if (v < nv) {
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (x[j][e] - mean) * rstd * p.gamma[v * 8 + e] + p.beta[v * 8 + e];
+      uint4 o;
+      o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]); o.z = pack2bf(y[4], y[5]); o.w = pack2bf(y[6], y[7]);
+      stg16(p.y + row * p.ldy + v * 8, o);
+    }
+  }
+}
+
+__global__ void ln_bwd_kernel(const lvd_ln_bwd_params p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int nv = p.c >> 3;
+  const float mean = p.mean_rstd[row * 2], rstd = p.mean_rstd[row * 2 + 1];
+  float xh[LN_MAXV][8], g[LN_MAXV][8];
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + 64 * j;
+    if (v < nv) {
+      uint4 r = ldg16(p.x + row * p.ldx + v * 8);
+      uint4 d = ldg16(p.dy + row * p.lddy + v * 8);
+      float xv[8] = {bflo(r.x), bfhi(r.x), bflo(r.y), bfhi(r.y), bflo(r.z), bfhi(r.z), bflo(r.w), bfhi(r.w)};
+      float dv[8] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y), bflo(d.z), bfhi(d.z), bflo(d.w), bfhi(d.w)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[j][e] = (xv[e] - mean) * rstd;
+        g[j][e] = dv[e] * p.gamma[v * 8 + e];
+        a += g[j][e]; b += g[j][e] * xh[j][e];
+      }
+    }
+  }
+  float m1 = wave_sum(a) / (float)p.c, m2 = wave_sum(b) / (float)p.c;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + 64 * j;
+    if (v < nv) {
+      float dx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dx[e] = rstd * (g[j][e] - m1 - xh[j][e] * m2);
+      lvd_bf16* o = p.dx + row * p.lddx + v * 8;
+      if (p.accumulate) {
+        uint4 r = ldg16(o);
+        dx[0] += bflo(r.x); dx[1] += bfhi(r.x); dx[2] += bflo(r.y); dx[3] += bfhi(r.y);
+        dx[4] += bflo(r.z); dx[5] += bfhi(r.z); dx[6] += bflo(r.w); dx[7] += bfhi(r.w);
+      }
+      uint4 w;
+      w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]); w.z = pack2bf(dx[4], dx[5]); w.w = pack2bf(dx[6], dx[7]);
+      stg16(o, w);
+    }
+  }
+}
+
+int gn_geometry(int c, int* VC, int* RL, int* threads) {
+  *VC = c / 4;
+  if (*VC > 1024) return 1;
+  *RL = 256 / *VC;
+  if (*RL < 1) *RL = 1;
+  *threads = ((*VC * *RL + 63) / 64) * 64;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream) {
+  LVD_CHECK(p && p->x1 && p->partial && p->scale_shift, "gn_stats: null pointer");
+  LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->c % p->groups == 0, "gn_stats: bad channels c=%d c1=%d groups=%d", p->c, p->c1, p->groups);
+  LVD_CHECK(p->rows % p->rows_per_sample == 0 && p->chunks > 0, "gn_stats: rows %% rows_per_sample");
+  LVD_CHECK(p->x2 != nullptr || p->c1 >= p->c, "gn_stats: missing second source");
+  int VC, RL, threads;
+  LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_stats: c too large");
+  int samples = p->rows / p->rows_per_sample;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 8 * sizeof(float), s, *p, VC, RL);
+  LVD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(samples * p->groups), dim3(64), 0, s, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_groupnorm_apply(const lvd_gn_apply_params* p, void* stream) {
+  LVD_CHECK(p && p->x1 && p->y && p->scale_shift, "gn_apply: null pointer");
+  LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0, "gn_apply: channels must be multiples of 8");
+  long total = (long)p->rows * (p->c / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void* stream) {
+  LVD_CHECK(p && p->x1 && p->dy && p->partial && p->gsum && p->mean_rstd, "gn_bwd_stats: null pointer");
+  LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->c % p->groups == 0, "gn_bwd_stats: bad channels");
+  int VC, RL, threads;
+  LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_bwd_stats: c too large");
+  int samples = p->rows / p->rows_per_sample;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 8 * sizeof(float), s, *p, VC, RL);
+  LVD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(samples * p->groups), dim3(64), 0, s, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream) {
+  LVD_CHECK(p && p->x1 && p->dy && p->dx1 && p->gsum, "gn_bwd_apply: null pointer");
+  LVD_CHECK(p->x2 == nullptr || p->dx2 != nullptr, "gn_bwd_apply: dx2 missing");
+  long total = (long)p->rows * (p->c / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_layernorm(const lvd_ln_params* p, void* stream) {
+  LVD_CHECK(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
+  LVD_CHECK(p->c % 8 == 0 && p->c <= 512 * LN_MAXV, "layernorm: c=%d unsupported (need c%%8==0, c<=%d)", p->c, 512 * LN_MAXV);
+  int blocks = (p->rows + 3) / 4;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_layernorm_bwd(const lvd_ln_bwd_params* p, void* stream) {
+  LVD_CHECK(p && p->x && p->dy && p->dx && p->gamma && p->mean_rstd, "layernorm_bwd: null pointer");
+  LVD_CHECK(p->c % 8 == 0 && p->c <= 512 * LN_MAXV, "layernorm_bwd: c=%d unsupported", p->c);
+  int blocks = (p->rows + 3) / 4;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}

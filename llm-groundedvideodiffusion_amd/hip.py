@@ -1,0 +1,194 @@
+"""ctypes binding of the C ABI declared in include/lvdhip.h.
+
+The library is built in-tree (``llm-groundedvideodiffusion_amd/liblvdhip.so``) by
+``__graft_entry__.build()`` / ``make -C llm-groundedvideodiffusion_amd/csrc``.  There is NO
+fallback: if the shared object is missing, or a kernel reports an error, a RuntimeError is raised
+(the reference's generate.py:343-348 error containment keeps working on RuntimeError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblvdhip.so")
+
+c_bf16_p = C.c_void_p
+c_f32_p = C.c_void_p
+c_i32_p = C.c_void_p
+i32 = C.c_int32
+f32 = C.c_float
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("a1", C.c_void_p), ("a2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("lda1", i32), ("lda2", i32), ("c1", i32), ("cin", i32), ("mode", i32),
+        ("hin", i32), ("win", i32), ("hout", i32), ("wout", i32), ("stride", i32), ("upsample", i32),
+        ("frames", i32), ("hw", i32), ("rows_per_sample", i32), ("ldres", i32), ("ldc", i32),
+        ("act", i32), ("out_fp32", i32), ("alpha", f32), ("accumulate", i32),
+    ]
+
+
+class GnStatsParams(C.Structure):
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p), ("ld1", i32), ("ld2", i32), ("c1", i32), ("c", i32),
+        ("rows", i32), ("rows_per_sample", i32), ("groups", i32), ("eps", f32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p), ("chunks", i32),
+        ("scale_shift", C.c_void_p), ("mean_rstd", C.c_void_p),
+    ]
+
+
+class GnApplyParams(C.Structure):
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p), ("ld1", i32), ("ld2", i32), ("c1", i32), ("c", i32),
+        ("rows", i32), ("rows_per_sample", i32), ("scale_shift", C.c_void_p), ("silu", i32),
+        ("y", C.c_void_p), ("ldy", i32),
+    ]
+
+
+class GnBwdStatsParams(C.Structure):
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p), ("ld1", i32), ("ld2", i32), ("c1", i32), ("c", i32),
+        ("dy", C.c_void_p), ("lddy", i32),
+        ("rows", i32), ("rows_per_sample", i32), ("groups", i32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p),
+        ("partial", C.c_void_p), ("chunks", i32), ("gsum", C.c_void_p), ("silu", i32),
+    ]
+
+
+class GnBwdApplyParams(C.Structure):
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p), ("ld1", i32), ("ld2", i32), ("c1", i32), ("c", i32),
+        ("dy", C.c_void_p), ("lddy", i32),
+        ("rows", i32), ("rows_per_sample", i32), ("groups", i32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p), ("gsum", C.c_void_p),
+        ("silu", i32),
+        ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("lddx1", i32), ("lddx2", i32), ("accumulate", i32),
+    ]
+
+
+class LnParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", i32), ("rows", i32), ("c", i32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", f32),
+        ("y", C.c_void_p), ("ldy", i32), ("mean_rstd", C.c_void_p),
+    ]
+
+
+class LnBwdParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", i32), ("dy", C.c_void_p), ("lddy", i32), ("rows", i32), ("c", i32),
+        ("gamma", C.c_void_p), ("mean_rstd", C.c_void_p), ("dx", C.c_void_p), ("lddx", i32), ("accumulate", i32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", i32), ("k", C.c_void_p), ("ldk", i32), ("v", C.c_void_p), ("ldv", i32),
+        ("k2", C.c_void_p), ("v2", C.c_void_p), ("ldk2", i32), ("ldv2", i32),
+        ("o", C.c_void_p), ("ldo", i32), ("lse", C.c_void_p),
+        ("samples", i32), ("heads", i32), ("sq", i32), ("skv", i32), ("skv2", i32),
+        ("q_ninner", i32), ("q_os", i32), ("q_is", i32), ("q_step", i32),
+        ("kv_ninner", i32), ("kv_os", i32), ("kv_is", i32), ("kv_step", i32),
+        ("kv2_ninner", i32), ("kv2_os", i32), ("kv2_is", i32), ("kv2_step", i32),
+        ("scale", f32),
+    ]
+
+
+class AttnBwdParams(C.Structure):
+    _fields_ = [
+        ("f", AttnParams),
+        ("d_o", C.c_void_p), ("lddo", i32), ("dq", C.c_void_p), ("lddq", i32),
+        ("dk", C.c_void_p), ("lddk", i32), ("dv", C.c_void_p), ("lddv", i32), ("delta", C.c_void_p),
+    ]
+
+
+class CaProbsParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", i32), ("k", C.c_void_p), ("ldk", i32),
+        ("frames", i32), ("heads", i32), ("P", i32), ("ntext", i32), ("scale", f32),
+        ("tok_ids", C.c_void_p), ("ntok", i32), ("probs", C.c_void_p), ("lse", C.c_void_p),
+    ]
+
+
+class CaSelectParams(C.Structure):
+    _fields_ = [
+        ("probs", C.c_void_p), ("dprobs", C.c_void_p),
+        ("frames", i32), ("heads", i32), ("P", i32), ("ntok", i32), ("H", i32), ("W", i32),
+        ("tok_obj", C.c_void_p), ("boxes", C.c_void_p), ("tok_weight", C.c_void_p), ("nobj", i32),
+        ("fg_top_p", f32), ("bg_top_p", f32), ("fg_weight", f32), ("bg_weight", f32), ("com_loss_scale", f32),
+        ("grad_scale", f32), ("loss_partial", C.c_void_p), ("com_ws", C.c_void_p),
+    ]
+
+
+class CaDqParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", i32), ("k", C.c_void_p), ("ldk", i32),
+        ("frames", i32), ("heads", i32), ("P", i32), ("ntext", i32), ("scale", f32),
+        ("tok_ids", C.c_void_p), ("ntok", i32),
+        ("probs", C.c_void_p), ("dprobs", C.c_void_p), ("lse", C.c_void_p),
+        ("dq", C.c_void_p), ("lddq", i32),
+    ]
+
+
+# name -> (argtypes) for every symbol include/lvdhip.h declares; restype is int unless noted
+_P = C.POINTER
+SYMBOLS = {
+    "lvdhip_last_error": None,
+    "lvdhip_version": [],
+    "lvdhip_gemm": [_P(GemmParams), C.c_void_p],
+    "lvdhip_groupnorm_stats": [_P(GnStatsParams), C.c_void_p],
+    "lvdhip_groupnorm_apply": [_P(GnApplyParams), C.c_void_p],
+    "lvdhip_groupnorm_bwd_stats": [_P(GnBwdStatsParams), C.c_void_p],
+    "lvdhip_groupnorm_bwd_apply": [_P(GnBwdApplyParams), C.c_void_p],
+    "lvdhip_layernorm": [_P(LnParams), C.c_void_p],
+    "lvdhip_layernorm_bwd": [_P(LnBwdParams), C.c_void_p],
+    "lvdhip_attention_fwd": [_P(AttnParams), C.c_void_p],
+    "lvdhip_attention_bwd": [_P(AttnBwdParams), C.c_void_p],
+    "lvdhip_ca_probs": [_P(CaProbsParams), C.c_void_p],
+    "lvdhip_ca_select": [_P(CaSelectParams), C.c_void_p],
+    "lvdhip_ca_dq": [_P(CaDqParams), C.c_void_p],
+    "lvdhip_latents_to_tokens": [C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, f32, C.c_void_p],
+    "lvdhip_tokens_to_latents": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, C.c_void_p],
+    "lvdhip_tokens_grad_to_latents": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, f32, C.c_void_p],
+    "lvdhip_add": [C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
+    "lvdhip_geglu_fwd": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
+    "lvdhip_geglu_bwd": [C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
+    "lvdhip_upsample2x_bwd": [C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p],
+    "lvdhip_timestep_embedding": [C.c_void_p, C.c_void_p, i32, i32, C.c_void_p],
+    "lvdhip_silu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "lvdhip_cfg_dpm_step": [C.c_void_p, C.c_void_p, f32, C.c_void_p, C.c_void_p, f32, f32, f32, f32, f32, C.c_int64, C.c_void_p],
+    "lvdhip_axpy": [C.c_void_p, C.c_void_p, f32, C.c_int64, C.c_void_p],
+    "lvdhip_reduce_sum": [C.c_void_p, C.c_int64, f32, C.c_void_p, C.c_void_p],
+}
+
+_lib = None
+
+
+def lib():
+    """Load liblvdhip.so once; raise loudly when it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path."
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            if name == "lvdhip_last_error":
+                fn.restype = C.c_char_p
+                fn.argtypes = []
+            else:
+                fn.restype = C.c_int
+                fn.argtypes = argtypes
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lvdhip_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"lvdhip {what} failed (rc={rc}): {msg}")

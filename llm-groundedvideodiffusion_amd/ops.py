@@ -1,0 +1,340 @@
+"""Tensor-level wrappers over the C ABI (include/lvdhip.h).
+
+PyTorch is used only as the device-memory container and stream provider: every function here takes
+2-D "token matrices" (rows = (batch, frame, y, x), channels contiguous, bf16) and launches the
+hand-written HIP kernels on torch's current stream.  Nothing in this file computes with torch ops.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import hip
+
+A_PLAIN, A_CONV3X3, A_TCONV3, A_CONV3X3_T2 = 0, 1, 2, 3
+ACT_NONE, ACT_GEGLU = 0, 1
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, f"expected row-major 2-D tensor, got {tuple(t.shape)} / {t.stride()}"
+    return t.stride(0)
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.bfloat16 and t.is_cuda, "bf16 CUDA tensor expected"
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), "contiguous fp32 CUDA tensor expected"
+
+
+@dataclass
+class ConvGeom:
+    hin: int
+    win: int
+    hout: int
+    wout: int
+    stride: int = 1
+    upsample: int = 0
+
+
+def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sample=0, res=None, out=None,
+         mode=A_PLAIN, conv: Optional[ConvGeom] = None, frames=0, hw=0, cin=None, act=ACT_NONE, out_fp32=False,
+         alpha=1.0, accumulate=False, m=None):
+    """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`."""
+    _chk_bf16(a1, a2, w, res)
+    _chk_f32(bias, rowbias)
+    N, K = w.shape if (n is None or k is None) else (n, k)
+    assert w.is_contiguous()
+    c1 = a1.shape[1]
+    c2 = a2.shape[1] if a2 is not None else 0
+    if cin is None:
+        cin = c1 + c2
+    if m is None:
+        m = a1.shape[0]
+        if mode in (A_CONV3X3, A_CONV3X3_T2):
+            nimg = a1.shape[0] // ((conv.hin >> conv.upsample) * (conv.win >> conv.upsample)) if mode == A_CONV3X3 else a1.shape[0] // (conv.hin * conv.win)
+            m = nimg * conv.hout * conv.wout
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty((m, n_out), dtype=torch.float32 if out_fp32 else torch.bfloat16, device=a1.device)
+    assert out.shape[0] == m and out.shape[1] >= n_out
+    p = hip.GemmParams()
+    p.a1, p.a2, p.w, p.bias, p.rowbias, p.res, p.out = _p(a1), _p(a2), _p(w), _p(bias), _p(rowbias), _p(res), _p(out)
+    p.M, p.N, p.K = m, N, K
+    p.lda1, p.lda2, p.c1, p.cin, p.mode = _ld(a1), (_ld(a2) if a2 is not None else 0), c1, cin, mode
+    if conv is not None:
+        p.hin, p.win, p.hout, p.wout, p.stride, p.upsample = conv.hin, conv.win, conv.hout, conv.wout, conv.stride, conv.upsample
+    p.frames, p.hw = frames, hw
+    p.rows_per_sample = rows_per_sample
+    p.ldres = _ld(res) if res is not None else 0
+    p.ldc = _ld(out)
+    p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
+    hip.check(hip.lib().lvdhip_gemm(C.byref(p), _stream()), "gemm")
+    return out
+
+
+def _gn_chunks(samples, rows_per_sample):
+    # enough workgroups to fill 256 CUs a few times over, but >= 64 rows per chunk
+    want = max(1, 2048 // max(samples, 1))
+    return max(1, min(want, rows_per_sample // 64 if rows_per_sample >= 64 else 1))
+
+
+def groupnorm_stats(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, x2=None):
+    """Returns (scale_shift [S,C,2], mean_rstd [S,G,2])."""
+    _chk_bf16(x1, x2)
+    _chk_f32(gamma, beta)
+    rows = x1.shape[0]
+    c1 = x1.shape[1]
+    c = c1 + (x2.shape[1] if x2 is not None else 0)
+    samples = rows // rows_per_sample
+    chunks = _gn_chunks(samples, rows_per_sample)
+    dev = x1.device
+    partial = torch.empty((samples, chunks, c, 2), dtype=torch.float32, device=dev)
+    ss = torch.empty((samples, c, 2), dtype=torch.float32, device=dev)
+    mr = torch.empty((samples, groups, 2), dtype=torch.float32, device=dev)
+    p = hip.GnStatsParams()
+    p.x1, p.x2, p.ld1, p.ld2, p.c1, p.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
+    p.rows, p.rows_per_sample, p.groups, p.eps = rows, rows_per_sample, groups, eps
+    p.gamma, p.beta, p.partial, p.chunks, p.scale_shift, p.mean_rstd = _p(gamma), _p(beta), _p(partial), chunks, _p(ss), _p(mr)
+    hip.check(hip.lib().lvdhip_groupnorm_stats(C.byref(p), _stream()), "groupnorm_stats")
+    return ss, mr
+
+
+def groupnorm_apply(x1, scale_shift, rows_per_sample, *, silu=False, x2=None, out=None):
+    _chk_bf16(x1, x2)
+    rows = x1.shape[0]
+    c1 = x1.shape[1]
+    c = c1 + (x2.shape[1] if x2 is not None else 0)
+    if out is None:
+        out = torch.empty((rows, c), dtype=torch.bfloat16, device=x1.device)
+    p = hip.GnApplyParams()
+    p.x1, p.x2, p.ld1, p.ld2, p.c1, p.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
+    p.rows, p.rows_per_sample, p.scale_shift, p.silu, p.y, p.ldy = rows, rows_per_sample, _p(scale_shift), int(silu), _p(out), _ld(out)
+    hip.check(hip.lib().lvdhip_groupnorm_apply(C.byref(p), _stream()), "groupnorm_apply")
+    return out
+
+
+def groupnorm(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None, return_stats=False):
+    ss, mr = groupnorm_stats(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, x2=x2)
+    y = groupnorm_apply(x1, ss, rows_per_sample, silu=silu, x2=x2, out=out)
+    return (y, mr) if return_stats else y
+
+
+def groupnorm_bwd(x1, dy, gamma, beta, mean_rstd, rows_per_sample, *, groups=32, silu=False, x2=None,
+                  dx1=None, dx2=None, accumulate=False):
+    """Input-gradient of groupnorm(+silu).  Returns (dx1, dx2)."""
+    _chk_bf16(x1, x2, dy)
+    rows = x1.shape[0]
+    c1 = x1.shape[1]
+    c = c1 + (x2.shape[1] if x2 is not None else 0)
+    samples = rows // rows_per_sample
+    chunks = _gn_chunks(samples, rows_per_sample)
+    dev = x1.device
+    partial = torch.empty((samples, chunks, c, 2), dtype=torch.float32, device=dev)
+    gsum = torch.empty((samples, groups, 2), dtype=torch.float32, device=dev)
+    p = hip.GnBwdStatsParams()
+    p.x1, p.x2, p.ld1, p.ld2, p.c1, p.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
+    p.dy, p.lddy = _p(dy), _ld(dy)
+    p.rows, p.rows_per_sample, p.groups = rows, rows_per_sample, groups
+    p.gamma, p.beta, p.mean_rstd, p.partial, p.chunks, p.gsum, p.silu = _p(gamma), _p(beta), _p(mean_rstd), _p(partial), chunks, _p(gsum), int(silu)
+    hip.check(hip.lib().lvdhip_groupnorm_bwd_stats(C.byref(p), _stream()), "groupnorm_bwd_stats")
+    if dx1 is None:
+        dx1 = torch.empty_like(x1)
+        assert not accumulate
+    if x2 is not None and dx2 is None:
+        dx2 = torch.empty_like(x2)
+    q = hip.GnBwdApplyParams()
+    q.x1, q.x2, q.ld1, q.ld2, q.c1, q.c = p.x1, p.x2, p.ld1, p.ld2, c1, c
+    q.dy, q.lddy = p.dy, p.lddy
+    q.rows, q.rows_per_sample, q.groups = rows, rows_per_sample, groups
+    q.gamma, q.beta, q.mean_rstd, q.gsum, q.silu = p.gamma, p.beta, p.mean_rstd, _p(gsum), int(silu)
+    q.dx1, q.dx2 = _p(dx1), _p(dx2)
+    q.lddx1, q.lddx2 = _ld(dx1), (_ld(dx2) if dx2 is not None else 0)
+    q.accumulate = int(accumulate)
+    hip.check(hip.lib().lvdhip_groupnorm_bwd_apply(C.byref(q), _stream()), "groupnorm_bwd_apply")
+    return dx1, dx2
+
+
+def layernorm(x, gamma, beta, *, eps=1e-5, out=None, return_stats=False):
+    _chk_bf16(x)
+    _chk_f32(gamma, beta)
+    rows, c = x.shape
+    if out is None:
+        out = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device)
+    mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if return_stats else None
+    p = hip.LnParams()
+    p.x, p.ldx, p.rows, p.c, p.gamma, p.beta, p.eps = _p(x), _ld(x), rows, c, _p(gamma), _p(beta), eps
+    p.y, p.ldy, p.mean_rstd = _p(out), _ld(out), _p(mr)
+    hip.check(hip.lib().lvdhip_layernorm(C.byref(p), _stream()), "layernorm")
+    return (out, mr) if return_stats else out
+
+
+def layernorm_bwd(x, dy, gamma, mean_rstd, *, dx=None, accumulate=False):
+    _chk_bf16(x, dy)
+    rows, c = x.shape
+    if dx is None:
+        dx = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device)
+        assert not accumulate
+    p = hip.LnBwdParams()
+    p.x, p.ldx, p.dy, p.lddy, p.rows, p.c = _p(x), _ld(x), _p(dy), _ld(dy), rows, c
+    p.gamma, p.mean_rstd, p.dx, p.lddx, p.accumulate = _p(gamma), _p(mean_rstd), _p(dx), _ld(dx), int(accumulate)
+    hip.check(hip.lib().lvdhip_layernorm_bwd(C.byref(p), _stream()), "layernorm_bwd")
+    return dx
+
+
+@dataclass
+class RowMap:
+    """Token row of element i of sample s = os*(s // ninner) + is_*(s % ninner) + step*i."""
+    ninner: int = 1
+    os: int = 0
+    is_: int = 0
+    step: int = 1
+
+
+def attn_params(q, k, v, o, *, samples, heads, sq, skv, qmap: RowMap, kvmap: RowMap, scale, lse=None,
+                k2=None, v2=None, skv2=0, kv2map: Optional[RowMap] = None):
+    _chk_bf16(q, k, v, o, k2, v2)
+    p = hip.AttnParams()
+    p.q, p.ldq, p.k, p.ldk, p.v, p.ldv = _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v)
+    p.k2, p.v2 = _p(k2), _p(v2)
+    p.ldk2, p.ldv2 = (_ld(k2) if k2 is not None else 0), (_ld(v2) if v2 is not None else 0)
+    p.o, p.ldo, p.lse = _p(o), _ld(o), _p(lse)
+    p.samples, p.heads, p.sq, p.skv, p.skv2 = samples, heads, sq, skv, skv2
+    p.q_ninner, p.q_os, p.q_is, p.q_step = qmap.ninner, qmap.os, qmap.is_, qmap.step
+    p.kv_ninner, p.kv_os, p.kv_is, p.kv_step = kvmap.ninner, kvmap.os, kvmap.is_, kvmap.step
+    m2 = kv2map or RowMap()
+    p.kv2_ninner, p.kv2_os, p.kv2_is, p.kv2_step = m2.ninner, m2.os, m2.is_, m2.step
+    p.scale = scale
+    return p
+
+
+def attention_fwd(q, k, v, o, **kw):
+    p = attn_params(q, k, v, o, **kw)
+    hip.check(hip.lib().lvdhip_attention_fwd(C.byref(p), _stream()), "attention_fwd")
+    return o
+
+
+def attention_bwd(q, k, v, o, lse, d_o, dq, dk, dv, **kw):
+    """dq always; dk/dv when given (None for text cross-attention)."""
+    _chk_bf16(d_o, dq, dk, dv)
+    b = hip.AttnBwdParams()
+    b.f = attn_params(q, k, v, o, lse=lse, **kw)
+    b.d_o, b.lddo, b.dq, b.lddq = _p(d_o), _ld(d_o), _p(dq), _ld(dq)
+    b.dk, b.lddk = _p(dk), (_ld(dk) if dk is not None else 0)
+    b.dv, b.lddv = _p(dv), (_ld(dv) if dv is not None else 0)
+    delta = torch.empty((kw["samples"], kw["heads"], kw["sq"]), dtype=torch.float32, device=q.device)
+    b.delta = _p(delta)
+    hip.check(hip.lib().lvdhip_attention_bwd(C.byref(b), _stream()), "attention_bwd")
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------ elementwise
+def latents_to_tokens(latents, cpad=8, scale=1.0, out=None):
+    _chk_f32(latents)
+    B, Cc, F, H, W = latents.shape
+    if out is None:
+        out = torch.empty((B * F * H * W, cpad), dtype=torch.bfloat16, device=latents.device)
+    hip.check(hip.lib().lvdhip_latents_to_tokens(_p(latents), _p(out), B, Cc, F, H * W, cpad, scale, _stream()), "latents_to_tokens")
+    return out
+
+
+def tokens_to_latents(tokens, B, Cc, F, H, W, out=None):
+    _chk_f32(tokens)
+    if out is None:
+        out = torch.empty((B, Cc, F, H, W), dtype=torch.float32, device=tokens.device)
+    hip.check(hip.lib().lvdhip_tokens_to_latents(_p(tokens), tokens.stride(0), _p(out), B, Cc, F, H * W, _stream()), "tokens_to_latents")
+    return out
+
+
+def tokens_grad_to_latents(tokens, B, Cc, F, H, W, scale=1.0, out=None):
+    _chk_bf16(tokens)
+    if out is None:
+        out = torch.empty((B, Cc, F, H, W), dtype=torch.float32, device=tokens.device)
+    hip.check(hip.lib().lvdhip_tokens_grad_to_latents(_p(tokens), _ld(tokens), _p(out), B, Cc, F, H * W, scale, _stream()), "tokens_grad_to_latents")
+    return out
+
+
+def add(a, b, out=None):
+    _chk_bf16(a, b)
+    if out is None:
+        out = torch.empty((a.shape[0], a.shape[1]), dtype=torch.bfloat16, device=a.device)
+    hip.check(hip.lib().lvdhip_add(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), a.shape[0], a.shape[1], _stream()), "add")
+    return out
+
+
+def geglu_fwd(pre, out=None):
+    _chk_bf16(pre)
+    rows, n2 = pre.shape
+    if out is None:
+        out = torch.empty((rows, n2 // 2), dtype=torch.bfloat16, device=pre.device)
+    hip.check(hip.lib().lvdhip_geglu_fwd(_p(pre), _ld(pre), _p(out), _ld(out), rows, n2 // 2, _stream()), "geglu_fwd")
+    return out
+
+
+def geglu_bwd(pre, dy, out=None):
+    _chk_bf16(pre, dy)
+    rows, n2 = pre.shape
+    if out is None:
+        out = torch.empty_like(pre)
+    hip.check(hip.lib().lvdhip_geglu_bwd(_p(pre), _ld(pre), _p(dy), _ld(dy), _p(out), _ld(out), rows, n2 // 2, _stream()), "geglu_bwd")
+    return out
+
+
+def upsample2x_bwd(dy, nimg, h, w, c, dx=None, accumulate=False):
+    _chk_bf16(dy)
+    assert dy.is_contiguous()
+    if dx is None:
+        dx = torch.empty((nimg * h * w, c), dtype=torch.bfloat16, device=dy.device)
+    assert dx.is_contiguous()
+    hip.check(hip.lib().lvdhip_upsample2x_bwd(_p(dy), _p(dx), nimg, h, w, c, int(accumulate), _stream()), "upsample2x_bwd")
+    return dx
+
+
+def timestep_embedding(t, dim):
+    _chk_f32(t)
+    out = torch.empty((t.numel(), dim), dtype=torch.bfloat16, device=t.device)
+    hip.check(hip.lib().lvdhip_timestep_embedding(_p(t), _p(out), t.numel(), dim, _stream()), "timestep_embedding")
+    return out
+
+
+def silu(x):
+    _chk_bf16(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    hip.check(hip.lib().lvdhip_silu(_p(x), _p(y), x.numel(), _stream()), "silu")
+    return y
+
+
+def cfg_dpm_step(eps_uncond, eps_cond, guidance_scale, x, x0_prev, alpha_t, sigma_t, c_x, c_0, c_1):
+    _chk_f32(eps_uncond, eps_cond, x, x0_prev)
+    hip.check(hip.lib().lvdhip_cfg_dpm_step(_p(eps_uncond), _p(eps_cond), guidance_scale, _p(x), _p(x0_prev), alpha_t, sigma_t,
+                                            c_x, c_0, c_1, x.numel(), _stream()), "cfg_dpm_step")
+    return x
+
+
+def axpy_(x, g, scale):
+    _chk_f32(x, g)
+    hip.check(hip.lib().lvdhip_axpy(_p(x), _p(g), scale, x.numel(), _stream()), "axpy")
+    return x
+
+
+def reduce_sum(x, scale=1.0, out=None):
+    _chk_f32(x)
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().lvdhip_reduce_sum(_p(x), x.numel(), scale, _p(out), _stream()), "reduce_sum")
+    return out

@@ -1,0 +1,335 @@
+"""Per-kernel parity: every HIP kernel (through the C ABI) vs a plain PyTorch fp32 reference of the
+same op on the same device.  Tolerances are bf16-level and written next to each check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import lvd_amd  # noqa: E402
+from lvd_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def close(a, b, tol, what=""):
+    e = relerr(a, b)
+    assert math.isfinite(e) and e < tol, f"{what}: rel-L2 {e:.3e} >= {tol}"
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 192, 320), (128, 128, 64), (1000, 640, 1288), (77, 320, 1024)])
+def test_gemm_plain(M, N, K):
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
+    ref = a.float() @ w.float().T
+    out = ops.gemm(a, w)
+    close(out, ref, 6e-3, "gemm plain")  # bf16 output rounding ~ 2^-9
+
+
+def test_gemm_detects_transpose():
+    # A = identity-like asymmetric check: B asymmetric so a swapped C write cannot pass
+    M = N = K = 128
+    a = torch.eye(M, device=DEV).to(torch.bfloat16)
+    w = bf(torch.arange(N * K, device=DEV).reshape(N, K).float() % 17 - 8)
+    out = ops.gemm(a, w, out_fp32=True)
+    assert torch.equal(out, w.float().T.contiguous()), "C layout / operand order wrong"
+
+
+def test_gemm_epilogue():
+    M, N, K, rps = 384, 320, 640, 96
+    a, w = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4, scale=0.05))
+    bias, rowb = rnd(N, seed=5), rnd(M // rps, N, seed=6)
+    res = bf(rnd(M, N, seed=7))
+    ref = res.float() + 0.37 * (a.float() @ w.float().T + bias + rowb.repeat_interleave(rps, 0))
+    out = ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, alpha=0.37)
+    close(out, ref, 6e-3, "gemm epilogue")
+    out32 = ops.gemm(a, w, bias=bias, out_fp32=True)
+    close(out32, a.float() @ w.float().T + bias, 1e-5, "gemm fp32 out")
+    acc = bf(rnd(M, N, seed=8))
+    ref2 = acc.float() + a.float() @ w.float().T
+    ops.gemm(a, w, out=acc, accumulate=True)
+    close(acc, ref2, 6e-3, "gemm accumulate")
+
+
+def test_gemm_concat_sources():
+    M, N, c1, c2 = 260, 128, 192, 64
+    a1, a2 = bf(rnd(M, c1, seed=1)), bf(rnd(M, c2, seed=2))
+    w = bf(rnd(N, c1 + c2, seed=3, scale=0.05))
+    ref = torch.cat([a1, a2], 1).float() @ w.float().T
+    out = ops.gemm(a1, w, a2=a2)
+    close(out, ref, 6e-3, "gemm concat")
+    # strided view as a source (column slice of a wider matrix)
+    wide = bf(rnd(M, 512, seed=9))
+    out = ops.gemm(wide[:, 128:128 + c1], w[:, :c1].contiguous())
+    close(out, wide[:, 128:128 + c1].float() @ w[:, :c1].float().T, 6e-3, "gemm strided A")
+
+
+def test_gemm_geglu():
+    M, K, inner = 200, 128, 256
+    a = bf(rnd(M, K, seed=1))
+    w = bf(rnd(2 * inner, K, seed=2, scale=0.08))  # torch layout: [hidden(inner) ; gate(inner)]
+    b = rnd(2 * inner, seed=3)
+    proj = a.float() @ w.float().T + b
+    ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+    from lvd_amd.weights import interleave_geglu
+    wi, bi = interleave_geglu(w, b)
+    out = ops.gemm(a, wi, bias=bi, act=ops.ACT_GEGLU)
+    close(out, ref, 6e-3, "gemm geglu")
+    pre = ops.gemm(a, wi, bias=bi)
+    close(ops.geglu_fwd(pre), ref, 8e-3, "geglu_fwd kernel")
+    dy = bf(rnd(M, inner, seed=4))
+    pre32 = pre.float().requires_grad_(True)
+    from lvd_amd.weights import deinterleave_geglu_cols
+    h, g = deinterleave_geglu_cols(pre32)
+    (h * F.gelu(g) * dy.float()).sum().backward()
+    close(ops.geglu_bwd(pre, dy), pre32.grad, 8e-3, "geglu_bwd kernel")
+
+
+def conv_w(cout, cin, seed):
+    return rnd(cout, cin, 3, 3, seed=seed, scale=0.05)
+
+
+def pack_conv(w):  # [cout,cin,3,3] -> [cout, 9*cin] tap-major
+    return bf(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
+
+
+def to_tokens(x):  # NCHW -> [(n,y,x), c]
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def from_tokens(t, n, h, w):
+    return t.reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("stride,upsample", [(1, 0), (2, 0), (1, 1)])
+def test_conv3x3(stride, upsample):
+    n, cin, cout, h, w = 3, 64, 96, 10, 18
+    x = bf(rnd(n, cin, h, w, seed=1)).float()
+    wt = bf(conv_w(cout, cin, 2)).float()
+    b = rnd(cout, seed=3)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if upsample else x
+    ref = F.conv2d(xin, wt, b, stride=stride, padding=1)
+    hin, win = xin.shape[-2:]
+    hout, wout = ref.shape[-2:]
+    out = ops.gemm(bf(to_tokens(x)), pack_conv(wt), bias=b, mode=ops.A_CONV3X3,
+                   conv=ops.ConvGeom(hin, win, hout, wout, stride, upsample))
+    close(from_tokens(out, n, hout, wout), ref, 6e-3, f"conv3x3 s{stride} up{upsample}")
+
+
+def test_conv3x3_concat_and_pad8():
+    n, c1, c2, cout, h, w = 2, 64, 32, 64, 8, 8
+    x1, x2 = bf(rnd(n, c1, h, w, seed=1)).float(), bf(rnd(n, c2, h, w, seed=2)).float()
+    wt = bf(conv_w(cout, c1 + c2, 3)).float()
+    ref = F.conv2d(torch.cat([x1, x2], 1), wt, None, padding=1)
+    out = ops.gemm(bf(to_tokens(x1)), pack_conv(wt), a2=bf(to_tokens(x2)), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, w, h, w))
+    close(from_tokens(out, n, h, w), ref, 6e-3, "conv concat")
+    # conv_in style: 4 channels padded to 8, K = 72 (not a multiple of the 64-wide K tile)
+    x = bf(rnd(n, 4, h, w, seed=4)).float()
+    wt4 = bf(conv_w(64, 4, 5)).float()
+    ref = F.conv2d(x, wt4, None, padding=1)
+    x8 = torch.cat([x, torch.zeros(n, 4, h, w, device=DEV)], 1)
+    w8 = torch.cat([wt4, torch.zeros(64, 4, 3, 3, device=DEV)], 1)
+    out = ops.gemm(bf(to_tokens(x8)), pack_conv(w8), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, w, h, w))
+    close(from_tokens(out, n, h, w), ref, 6e-3, "conv_in pad8")
+
+
+def test_conv_dgrad():
+    n, cin, cout, h, w = 2, 64, 96, 12, 10
+    x = bf(rnd(n, cin, h, w, seed=1)).float().requires_grad_(True)
+    wt = bf(conv_w(cout, cin, 2)).float()
+    from lvd_amd.weights import pack_conv3x3_dgrad, pack_conv3x3_dgrad_t2
+    for stride in (1, 2):
+        y = F.conv2d(x, wt, None, stride=stride, padding=1)
+        dy = bf(rnd(*y.shape, seed=3)).float()
+        (gref,) = torch.autograd.grad(y, x, dy)
+        ho, wo = y.shape[-2:]
+        if stride == 1:
+            out = ops.gemm(bf(to_tokens(dy)), pack_conv3x3_dgrad(wt), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, w, h, w))
+        else:
+            out = ops.gemm(bf(to_tokens(dy)), pack_conv3x3_dgrad_t2(wt), mode=ops.A_CONV3X3_T2,
+                           conv=ops.ConvGeom(ho, wo, h, w), m=n * h * w)
+        close(from_tokens(out, n, h, w), gref, 6e-3, f"conv dgrad s{stride}")
+    # nearest-upsample backward
+    dyu = bf(rnd(n * 2 * h * 2 * w, cin, seed=5))
+    ref = F.avg_pool2d(from_tokens(dyu.float(), n, 2 * h, 2 * w), 2) * 4
+    close(from_tokens(ops.upsample2x_bwd(dyu, n, h, w, cin), n, h, w), ref, 6e-3, "upsample bwd")
+
+
+def test_tconv3():
+    B, Fr, hw, cin, cout = 2, 5, 12, 64, 64
+    x = bf(rnd(B * Fr * hw, cin, seed=1))
+    wt = bf(rnd(cout, cin, 3, seed=2, scale=0.05)).float()  # Conv3d (3,1,1) weight [cout,cin,3]
+    b = rnd(cout, seed=3)
+    x5 = x.float().reshape(B, Fr, hw, cin).permute(0, 3, 1, 2)[..., None]  # (B,C,F,hw,1)
+    ref = F.conv3d(x5, wt[..., None, None], b, padding=(1, 0, 0))
+    ref_tok = ref[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * hw, cout)
+    wp = bf(wt.permute(0, 2, 1).reshape(cout, 3 * cin).contiguous())
+    res = bf(rnd(B * Fr * hw, cout, seed=4))
+    out = ops.gemm(x, wp, bias=b, mode=ops.A_TCONV3, frames=Fr, hw=hw, res=res)
+    close(out, ref_tok + res.float(), 6e-3, "tconv3")
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C,rps,samples,two", [(320, 180, 6, False), (64, 96, 4, False), (960, 45, 8, True), (128, 2 * 96, 2, False)])
+def test_groupnorm(C, rps, samples, two):
+    rows = rps * samples
+    x = bf(rnd(rows, C, seed=1) * 2 + 0.5)
+    gamma, beta = rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.2
+    xr = x.float().reshape(samples, rps, C).permute(0, 2, 1)
+    for silu in (False, True):
+        ref = F.group_norm(xr, 32, gamma, beta, 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        ref = ref.permute(0, 2, 1).reshape(rows, C)
+        if two:
+            c1 = 640
+            y, mr = ops.groupnorm(x[:, :c1].contiguous(), gamma, beta, rps, silu=silu, x2=x[:, c1:].contiguous(), return_stats=True)
+        else:
+            y, mr = ops.groupnorm(x, gamma, beta, rps, silu=silu, return_stats=True)
+        close(y, ref, 6e-3, f"groupnorm C={C} silu={silu}")
+    # backward vs autograd
+    xa = x.float().requires_grad_(True)
+    yy = F.silu(F.group_norm(xa.reshape(samples, rps, C).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, C)
+    dy = bf(rnd(rows, C, seed=4))
+    (gref,) = torch.autograd.grad(yy, xa, dy.float())
+    if two:
+        c1 = 640
+        d1, d2 = ops.groupnorm_bwd(x[:, :c1].contiguous(), dy, gamma, beta, mr, rps, silu=True, x2=x[:, c1:].contiguous())
+        got = torch.cat([d1, d2], 1)
+    else:
+        got, _ = ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, silu=True)
+    close(got, gref, 1e-2, f"groupnorm bwd C={C}")
+
+
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layernorm(C):
+    rows = 333
+    x = bf(rnd(rows, C, seed=1) * 1.5 + 0.3)
+    gamma, beta = rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.2
+    y, mr = ops.layernorm(x, gamma, beta, return_stats=True)
+    close(y, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), 6e-3, "layernorm")
+    xa = x.float().requires_grad_(True)
+    dy = bf(rnd(rows, C, seed=4))
+    (gref,) = torch.autograd.grad(F.layer_norm(xa, (C,), gamma, beta, 1e-5), xa, dy.float())
+    close(ops.layernorm_bwd(x, dy, gamma, mr), gref, 1e-2, "layernorm bwd")
+
+
+# ----------------------------------------------------------------------------- attention
+def sdpa_ref(q, k, v, scale):  # [S, H, L, 64] fp32
+    s = torch.einsum("shqd,shkd->shqk", q, k) * scale
+    return torch.einsum("shqk,shkd->shqd", s.softmax(-1), v), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("sq", [45, 100, 720])
+def test_attention_spatial(sq):
+    S, H = 3, 2
+    C = H * 64
+    qkv = bf(rnd(S * sq, 3 * C, seed=1))
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o = torch.zeros(S * sq, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(S, H, sq, device=DEV)
+    ops.attention_fwd(q, k, v, o, samples=S, heads=H, sq=sq, skv=sq, qmap=ops.RowMap(1, sq, 0, 1), kvmap=ops.RowMap(1, sq, 0, 1),
+                      scale=0.125, lse=lse)
+    split = lambda t: t.float().reshape(S, sq, H, 64).permute(0, 2, 1, 3)
+    ref, lref = sdpa_ref(split(q), split(k), split(v), 0.125)
+    close(o, ref.permute(0, 2, 1, 3).reshape(S * sq, C), 8e-3, "attn spatial")
+    close(lse, lref, 1e-3, "attn lse")
+
+
+def test_attention_cross_and_two_segments():
+    Bt, Fr, sq, H, nt = 2, 3, 50, 2, 77
+    C = H * 64
+    S = Bt * Fr
+    q = bf(rnd(S * sq, C, seed=1))
+    kv = bf(rnd(Bt * nt, 2 * C, seed=2))
+    k, v = kv[:, :C], kv[:, C:]
+    o = torch.zeros(S * sq, C, dtype=torch.bfloat16, device=DEV)
+    ops.attention_fwd(q, k, v, o, samples=S, heads=H, sq=sq, skv=nt, qmap=ops.RowMap(1, sq, 0, 1), kvmap=ops.RowMap(Fr, nt, 0, 1), scale=0.125)
+    qs = q.float().reshape(S, sq, H, 64).permute(0, 2, 1, 3)
+    ks = k.float().reshape(Bt, nt, H, 64).permute(0, 2, 1, 3).repeat_interleave(Fr, 0)
+    vs = v.float().reshape(Bt, nt, H, 64).permute(0, 2, 1, 3).repeat_interleave(Fr, 0)
+    ref, _ = sdpa_ref(qs, ks, vs, 0.125)
+    close(o, ref.permute(0, 2, 1, 3).reshape(S * sq, C), 8e-3, "attn cross")
+    # GLIGEN-style: keys = [sq visual tokens of the frame ; 30 grounding tokens of the frame]
+    no = 30
+    qkv = bf(rnd(S * sq, 3 * C, seed=3))
+    okv = bf(rnd(S * no, 2 * C, seed=4))
+    o2 = torch.zeros(S * sq, C, dtype=torch.bfloat16, device=DEV)
+    ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o2, samples=S, heads=H, sq=sq, skv=sq,
+                      qmap=ops.RowMap(1, sq, 0, 1), kvmap=ops.RowMap(1, sq, 0, 1), scale=0.125,
+                      k2=okv[:, :C], v2=okv[:, C:], skv2=no, kv2map=ops.RowMap(1, no, 0, 1))
+    sp = lambda t, L: t.float().reshape(S, L, H, 64).permute(0, 2, 1, 3)
+    kk = torch.cat([sp(qkv[:, C:2 * C], sq), sp(okv[:, :C], no)], 2)
+    vv = torch.cat([sp(qkv[:, 2 * C:], sq), sp(okv[:, C:], no)], 2)
+    ref, _ = sdpa_ref(sp(qkv[:, :C], sq), kk, vv, 0.125)
+    close(o2, ref.permute(0, 2, 1, 3).reshape(S * sq, C), 8e-3, "attn two segments")
+
+
+def test_attention_temporal():
+    Bt, Fr, hw, H = 2, 24, 20, 3
+    C = H * 64
+    rows = Bt * Fr * hw
+    qkv = bf(rnd(rows, 3 * C, seed=1))
+    o = torch.zeros(rows, C, dtype=torch.bfloat16, device=DEV)
+    tm = ops.RowMap(hw, Fr * hw, 1, hw)
+    ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, samples=Bt * hw, heads=H, sq=Fr, skv=Fr, qmap=tm, kvmap=tm, scale=0.125)
+    sp = lambda t: t.float().reshape(Bt, Fr, hw, H, 64).permute(0, 2, 3, 1, 4).reshape(Bt * hw, H, Fr, 64)
+    ref, _ = sdpa_ref(sp(qkv[:, :C]), sp(qkv[:, C:2 * C]), sp(qkv[:, 2 * C:]), 0.125)
+    ref = ref.reshape(Bt, hw, H, Fr, 64).permute(0, 3, 1, 2, 4).reshape(rows, C)
+    close(o, ref, 8e-3, "attn temporal")
+
+
+def test_attention_softmax_rescale_spike():
+    # force the online-softmax rescale branch: one key dominates late in the sequence
+    S, H, sq = 1, 1, 96
+    q = bf(rnd(sq, 64, seed=1))
+    k = bf(rnd(sq, 64, seed=2))
+    k[80] = q[5] * 4
+    v = bf(rnd(sq, 64, seed=3))
+    o = torch.zeros(sq, 64, dtype=torch.bfloat16, device=DEV)
+    ops.attention_fwd(q, k, v, o, samples=1, heads=1, sq=sq, skv=sq, qmap=ops.RowMap(1, sq, 0, 1), kvmap=ops.RowMap(1, sq, 0, 1), scale=0.125)
+    ref, _ = sdpa_ref(q.float()[None, None], k.float()[None, None], v.float()[None, None], 0.125)
+    close(o, ref[0, 0], 8e-3, "attn spike")
+
+
+# ----------------------------------------------------------------------------- elementwise
+def test_elementwise():
+    B, Cc, Fr, h, w = 2, 4, 3, 4, 6
+    lat = rnd(B, Cc, Fr, h, w, seed=1)
+    tok = ops.latents_to_tokens(lat, cpad=8)
+    ref = lat.permute(0, 2, 3, 4, 1).reshape(-1, Cc)
+    assert torch.equal(tok[:, :4].float(), bf(ref).float()) and tok[:, 4:].abs().max() == 0
+    t32 = rnd(B * Fr * h * w, 8, seed=2)
+    back = ops.tokens_to_latents(t32, B, Cc, Fr, h, w)
+    assert torch.equal(back, t32[:, :4].reshape(B, Fr, h, w, Cc).permute(0, 4, 1, 2, 3))
+    g = ops.tokens_grad_to_latents(bf(t32), B, Cc, Fr, h, w, scale=2.0)
+    assert torch.allclose(g, 2 * bf(t32)[:, :4].float().reshape(B, Fr, h, w, Cc).permute(0, 4, 1, 2, 3))
+    a, b = bf(rnd(50, 64, seed=3)), bf(rnd(50, 64, seed=4))
+    close(ops.add(a, b), a.float() + b.float(), 4e-3, "add")
+    t = torch.tensor([999.0, 37.0], device=DEV)
+    emb = ops.timestep_embedding(t, 320)
+    half = 160
+    fr = torch.exp(-math.log(10000) * torch.arange(half, device=DEV) / half)
+    ang = t[:, None] * fr[None]
+    close(emb, torch.cat([ang.cos(), ang.sin()], -1), 6e-3, "timestep embedding")
+    x = bf(rnd(10, 64, seed=5))
+    close(ops.silu(x), F.silu(x.float()), 6e-3, "silu")
+    v = rnd(1000, seed=6)
+    assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
