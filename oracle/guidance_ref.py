@@ -1,0 +1,111 @@
+"""ORACLE (test infrastructure only) — restatement of the cross-attention-energy guidance.
+
+Follows, on any device and in fp32:
+  scale_proportion                    /root/reference/utils/utils.py:82-103   (python banker's round)
+  get_hw_from_attn_dim                /root/reference/utils/utils.py:253-256
+  add_ca_loss_per_attn_map_to_loss    /root/reference/utils/guidance.py:160-526 (max-based top-k terms :328-353,
+                                      centre-of-mass + velocity terms :468-522, per-object token normalisation :524)
+  compute_ca_lossv3                   /root/reference/utils/guidance.py:529-574
+  latent_backward_guidance            /root/reference/models/pipelines.py:21-150
+Only the branches the video entry points use are restated (max-based loss, upsample_scale=1, no smoothing /
+renorm / ratio / CE / attn-sync / BoxDiff).  Pinned by tests/golden/guidance_*.npz generated from the shimmed
+reference import (oracle/make_golden.py).
+"""
+import math
+
+import torch
+
+
+def scale_proportion(box, H, W):
+    x_min, y_min = round(box[0] * W), round(box[1] * H)
+    bw, bh = round((box[2] - box[0]) * W), round((box[3] - box[1]) * H)
+    x_max, y_max = x_min + bw, y_min + bh
+    return max(x_min, 0), max(y_min, 0), min(x_max, W), min(y_max, H)
+
+
+def get_hw_from_attn_dim(attn_dim, base_attn_dim):
+    scale = int(math.sqrt((base_attn_dim[0] * base_attn_dim[1]) / attn_dim))
+    return base_attn_dim[0] // scale, base_attn_dim[1] // scale
+
+
+def _com(x, h_range, w_range):
+    tot = x.sum(dim=(1, 2))
+    return (x.sum(dim=2) * h_range).sum(-1) / tot, (x.sum(dim=1) * w_range).sum(-1) / tot
+
+
+def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                    bg_weight=1.0, com_loss_scale=0.0):
+    """attn_map: (frames, heads, P, tokens) probabilities.  Returns the un-normalised loss contribution."""
+    n_f, heads, P, _ = attn_map.shape
+    H, W = get_hw_from_attn_dim(P, base_attn_dim)
+    dev = attn_map.device
+    h_range = torch.arange(H, device=dev, dtype=torch.float32)[None]
+    w_range = torch.arange(W, device=dev, dtype=torch.float32)[None]
+    loss = torch.zeros((), device=dev)
+    for obj_idx, obj_boxes in enumerate(bboxes):
+        assert len(obj_boxes) == n_f
+        obj_loss = 0
+        for f, box in enumerate(obj_boxes):
+            f1 = min(f + 1, n_f - 1)
+            mask = torch.zeros(H, W, device=dev)
+            x0, y0, x1, y1 = scale_proportion(box, H, W)
+            mask[y0:y1, x0:x1] = 1
+            mask_t1 = torch.zeros(H, W, device=dev)
+            x0, y0, x1, y1 = scale_proportion(obj_boxes[f1], H, W)
+            mask_t1[y0:y1, x0:x1] = 1
+            k_fg = int((mask.sum() * fg_top_p).long().clamp_(min=1))
+            k_bg = int(((1 - mask).sum() * bg_top_p).long().clamp_(min=1))
+            m1 = mask.view(1, -1)
+            for pos in object_positions[obj_idx]:
+                a = attn_map[f, :, :, pos].float()      # (heads, P)
+                a1 = attn_map[f1, :, :, pos].float()
+                obj_loss = obj_loss + fg_weight * (1 - (a * m1).topk(k_fg).values.mean(1)).sum(0)
+                obj_loss = obj_loss + bg_weight * (a * (1 - m1)).topk(k_bg).values.mean(1).sum(0)
+                if com_loss_scale > 0 and mask.sum() > 0:
+                    ch, cw = _com(a.view(heads, H, W), h_range, w_range)
+                    mh, mw = _com(mask[None], h_range, w_range)
+                    obj_loss = obj_loss + com_loss_scale * (((ch - mh) ** 2).mean() + ((cw - mw) ** 2).mean())
+                    if mask_t1.sum() > 0:
+                        ch1, cw1 = _com(a1.view(heads, H, W), h_range, w_range)
+                        mh1, mw1 = _com(mask_t1[None], h_range, w_range)
+                        obj_loss = obj_loss + com_loss_scale * ((((ch1 - ch) - (mh1 - mh)) ** 2).mean() + (((cw1 - cw) - (mw1 - mw)) ** 2).mean())
+        loss = loss + obj_loss / len(object_positions[obj_idx])
+    return loss
+
+
+def compute_ca_loss(saved_attn, bboxes, object_positions, guidance_attn_keys, base_attn_dim, **kw):
+    """compute_ca_lossv3: mean over objects and keys of the per-map energies."""
+    dev = next(iter(saved_attn.values())).device if saved_attn else "cpu"
+    loss = torch.zeros((), device=dev)
+    n_obj = len(bboxes)
+    if n_obj == 0:
+        return loss
+    for key in guidance_attn_keys:
+        loss = loss + ca_loss_per_map(saved_attn[key], bboxes, object_positions, base_attn_dim, **kw)
+    if len(guidance_attn_keys) > 0:
+        loss = loss / (n_obj * len(guidance_attn_keys))
+    return loss
+
+
+def latent_backward_guidance(unet_fn, alphas_cumprod, cond_embeddings, index, bboxes, object_positions, t, latents, loss,
+                             loss_scale=30.0, loss_threshold=0.2, max_iter=5, max_index_step=10, guidance_attn_keys=None,
+                             base_attn_dim=(40, 72), **loss_kw):
+    """models/pipelines.py:21-150.  `unet_fn(latents, t, cond, save_dict, save_keys)` runs the cond-branch forward and
+    fills save_dict; `loss` is the carried (scaled) loss tensor/float.  Returns (latents, loss)."""
+    iteration = 0
+    loss_val = float(loss)
+    if index < max_index_step:
+        if isinstance(max_iter, list):
+            max_iter = max_iter[index]
+        while loss_val / loss_scale > loss_threshold and iteration < max_iter:
+            saved = {}
+            lat = latents.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                unet_fn(lat, t, cond_embeddings, saved, guidance_attn_keys)
+                l = compute_ca_loss(saved, bboxes, object_positions, guidance_attn_keys, base_attn_dim, **loss_kw) * loss_scale
+                (grad,) = torch.autograd.grad(l, [lat])
+            scale = (1 - float(alphas_cumprod[int(t)])) ** 0.5
+            latents = latents.detach() - scale * grad
+            loss_val = float(l.detach())
+            iteration += 1
+    return latents, loss_val
