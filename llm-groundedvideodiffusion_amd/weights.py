@@ -78,13 +78,13 @@ def _tblock(d, name, dim, cross_dim, double_self, gated, fuser_ctx):
     _ff(d, name + ".ff", dim)
     if gated:
         f = name + ".fuser"
+        d[f + ".alpha_attn"] = ()  # own parameters precede sub-module parameters in state_dict()
+        d[f + ".alpha_dense"] = ()
         _lin(d, f + ".linear", dim, fuser_ctx)
         _attn(d, f + ".attn", dim, dim)
         _ff(d, f + ".ff", dim)
         _norm(d, f + ".norm1", dim)
         _norm(d, f + ".norm2", dim)
-        d[f + ".alpha_attn"] = ()
-        d[f + ".alpha_dense"] = ()
 
 
 def _transformer2d(d, name, c, cfg):
@@ -147,13 +147,6 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
         if i != len(boc) - 1:
             d[f"{name}.downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
             d[f"{name}.downsamplers.0.conv.bias"] = (out_c,)
-    c = boc[-1]
-    _resnet(d, "mid_block.resnets.0", c, c, temb)
-    _resnet(d, "mid_block.resnets.1", c, c, temb)
-    _temp_conv(d, "mid_block.temp_convs.0", c)
-    _temp_conv(d, "mid_block.temp_convs.1", c)
-    _transformer2d(d, "mid_block.attentions.0", c, cfg)
-    _transformer_temporal(d, "mid_block.temp_attentions.0", c, c)
     rev = list(reversed(boc))
     out_c = rev[0]
     for i, btype in enumerate(cfg.up_block_types):
@@ -177,17 +170,25 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
         if i != len(boc) - 1:
             d[f"{name}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
             d[f"{name}.upsamplers.0.conv.bias"] = (out_c,)
+    # mid_block is registered after up_blocks in the reference module (unet_3d_condition.py:323-356)
+    c = boc[-1]
+    _resnet(d, "mid_block.resnets.0", c, c, temb)
+    _resnet(d, "mid_block.resnets.1", c, c, temb)
+    _temp_conv(d, "mid_block.temp_convs.0", c)
+    _temp_conv(d, "mid_block.temp_convs.1", c)
+    _transformer2d(d, "mid_block.attentions.0", c, cfg)
+    _transformer_temporal(d, "mid_block.temp_attentions.0", c, c)
     _norm(d, "conv_norm_out", boc[0])
     d["conv_out.weight"] = (cfg.out_channels, boc[0], 3, 3)
     d["conv_out.bias"] = (cfg.out_channels,)
     if cfg.gated:
         pl = cfg.cross_attention_dim
         pos_dim = 8 * 2 * 4  # fourier_freqs * (sin, cos) * xyxy
+        d["position_net.null_positive_feature"] = (pl,)
+        d["position_net.null_position_feature"] = (pos_dim,)
         _lin(d, "position_net.linears.0", 512, pl + pos_dim)
         _lin(d, "position_net.linears.2", 512, 512)
         _lin(d, "position_net.linears.4", cfg.cross_attention_dim, 512)
-        d["position_net.null_positive_feature"] = (pl,)
-        d["position_net.null_position_feature"] = (pos_dim,)
     return d
 
 

@@ -1,0 +1,110 @@
+"""CPU tests: the oracle (oracle/*.py, a restatement) against golden vectors produced by importing the real
+reference (tests/golden/*.npz, generator oracle/make_golden.py).  fp32 vs fp32: tolerance 2e-4 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lvd_amd  # noqa: F401
+from lvd_amd.weights import TINY, UNetConfig, synthetic_state_dict, unet_param_shapes
+from oracle import guidance_ref, scheduler_ref, unet_ref
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_param_names_match_reference():
+    g = np.load(os.path.join(G, "unet_tiny.npz"))
+    shapes = unet_param_shapes(UNetConfig(**TINY))
+    assert list(shapes.keys()) == list(g["param_names"])
+    numel = [int(np.prod(s)) if len(s) else 1 for s in shapes.values()]
+    assert numel == list(g["param_numel"])
+
+
+def test_zeroscope_param_count():
+    # default (zeroscope) topology = 1411.2 M parameters, 1623.8 M with GLIGEN fusers
+    n = sum(int(np.prod(s)) if len(s) else 1 for s in unet_param_shapes(UNetConfig()).values())
+    ng = sum(int(np.prod(s)) if len(s) else 1 for s in unet_param_shapes(UNetConfig(attention_type="gated")).values())
+    assert abs(n / 1e6 - 1411.2) < 0.5 and abs(ng / 1e6 - 1623.8) < 0.5, (n, ng)
+
+
+def test_unet_forward_matches_reference():
+    g = np.load(os.path.join(G, "unet_tiny.npz"))
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=0)
+    saved = {}
+    keys = [("down", 1, 0, 0), ("down", 2, 0, 0), ("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 2, 1, 0)]
+    with torch.no_grad():
+        out = unet_ref.unet_forward(sd, cfg, torch.from_numpy(g["sample"]), int(g["timestep"]), torch.from_numpy(g["ehs"]),
+                                    save_attn_to_dict=saved, save_keys=keys)
+    assert rel(out, g["out"]) < 2e-4
+    for k in keys:
+        assert rel(saved[k], g["attn_" + "_".join(map(str, k))]) < 2e-4, k
+
+
+def test_unet_gated_matches_reference():
+    g = np.load(os.path.join(G, "unet_tiny_gated.npz"))
+    cfg = UNetConfig(attention_type="gated", **TINY)
+    sd = synthetic_state_dict(cfg, seed=1)
+    gl = {k: torch.from_numpy(g[k]) for k in ("boxes", "masks", "positive_embeddings")}
+    with torch.no_grad():
+        out = unet_ref.unet_forward(sd, cfg, torch.from_numpy(g["sample"]), int(g["timestep"]), torch.from_numpy(g["ehs"]), gligen=gl)
+        out_off = unet_ref.unet_forward(sd, cfg, torch.from_numpy(g["sample"]), int(g["timestep"]), torch.from_numpy(g["ehs"]), gligen=gl, fuser_enabled=False)
+    assert rel(out, g["out"]) < 2e-4
+    assert rel(out_off, g["out"]) > 1e-2  # the fusers really contribute (non-zero alpha in the synthetic weights)
+
+
+@pytest.mark.parametrize("case,kw", [
+    ("topk", dict(fg_top_p=0.75, bg_top_p=0.75, fg_weight=1.0, bg_weight=4.0, com_loss_scale=0.0)),
+    ("com", dict(fg_top_p=0.25, bg_top_p=0.25, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03)),
+])
+def test_guidance_loss_matches_reference(case, kw):
+    g = np.load(os.path.join(G, "guidance_loss.npz"))
+    maps = {("down", 1, 0, 0): torch.from_numpy(g["maps_0"])[0].requires_grad_(True), ("up", 1, 1, 0): torch.from_numpy(g["maps_1"])[0].requires_grad_(True)}
+    bboxes = g["bboxes"].tolist()
+    loss = guidance_ref.compute_ca_loss(maps, bboxes, [[2, 3], [6]], list(maps.keys()), (8, 12), **kw)
+    assert abs(loss.item() - float(g[f"loss_{case}"])) < 1e-4 * abs(float(g[f"loss_{case}"]))
+    g0, g1 = torch.autograd.grad(loss, list(maps.values()))
+    assert rel(g0, g[f"grad0_{case}"][0]) < 1e-4 and rel(g1, g[f"grad1_{case}"][0]) < 1e-4
+
+
+def test_guidance_step_matches_reference():
+    g = np.load(os.path.join(G, "guidance_step.npz"))
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=0)
+    keys = [tuple(int(x) if x.isdigit() else x for x in k.split("_")) for k in g["keys"]]
+    sched = scheduler_ref.DPMSolverPP2M()
+
+    def unet_fn(lat, t, cond, save, save_keys):
+        unet_ref.unet_forward(sd, cfg, lat, int(t), cond, save_attn_to_dict=save, save_keys=save_keys, stop_after_key=keys[-1])
+
+    hp = dict(loss_scale=5.0, loss_threshold=0.01, max_index_step=10, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0,
+              com_loss_scale=0.03, base_attn_dim=(16, 16), guidance_attn_keys=keys)
+    for iters, suffix in ((1, "_1"), (2, "")):
+        lat, loss = guidance_ref.latent_backward_guidance(unet_fn, sched.alphas_cumprod, torch.from_numpy(g["cond"]), 0, g["bboxes"].tolist(),
+                                                          [[2]], int(g["t"]), torch.from_numpy(g["latents_in"]), 10000.0, max_iter=iters, **hp)
+        assert abs(loss - float(g["loss" + suffix])) < 2e-4 * abs(float(g["loss" + suffix]))
+        d_ref = torch.from_numpy(g["latents_out" + suffix]) - torch.from_numpy(g["latents_in"])
+        assert rel(lat - torch.from_numpy(g["latents_in"]), d_ref) < 2e-3
+
+
+def test_scheduler_properties():
+    s = scheduler_ref.DPMSolverPP2M()
+    s.set_timesteps(40)
+    assert len(s.timesteps) == 40 and s.timesteps[0] == 999 and s.sigmas[-1] == 0
+    # a perfect noise prediction makes every step land on the clean sample scaled by alpha of the next step
+    x0 = torch.randn(3, 4, generator=torch.Generator().manual_seed(0))
+    noise = torch.randn(3, 4, generator=torch.Generator().manual_seed(1))
+    a, sg = s._alpha_sigma(float(s.sigmas[0]))
+    x = a * x0 + sg * noise
+    for _ in range(40):
+        i = s.step_index
+        a, sg = s._alpha_sigma(float(s.sigmas[i]))
+        eps = (x - a * x0) / sg
+        x = s.step(eps, x)
+    assert torch.allclose(x, x0, atol=1e-4)
