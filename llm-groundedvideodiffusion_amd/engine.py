@@ -1,0 +1,514 @@
+"""Token-matrix executor of the UNet3D denoiser on MI355X.
+
+Design (MI355X-first, not a module-by-module port of models/unet_3d_condition.py):
+  * every activation is ONE row-major bf16 matrix [rows, C] with rows = (batch, frame, y, x).  Linear layers,
+    3x3 convs (implicit GEMM), temporal convs (3 shifted taps of the same matrix) and the skip-connection
+    concat (two-source A operand) are all the same MFMA GEMM kernel; the reference's NCHW<->NLC permutes
+    (transformer_2d.py:317-326,362-370), (B·F,C,H,W)<->(B,C,F,H,W) reshapes (unet_3d_condition.py:726-728,
+    transformer_temporal.py:148-156,175-182, TemporalConvLayer) and torch.cat (unet_3d_blocks.py:641,736) never
+    touch HBM — spatial and temporal attention address the same matrix with different row strides.
+  * text keys/values of all cross-attention layers are projected once per prompt (TextCache): the reference
+    recomputes to_k/to_v on the frame-repeated text for every frame, layer and step
+    (unet_3d_condition.py:721-723 + attention_processor.py:387-399).
+  * the guidance pass records a static tape of kernel launches; backward() replays hand-written
+    input-gradient kernels in reverse (no autograd graph, parameter gradients are never formed), and the
+    forward stops right after the query projection of the last guidance key (the reference runs the whole UNet,
+    models/pipelines.py:99 TODO).
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from .weights import UNetConfig, interleave_geglu, pack_conv3x3, pack_tconv3
+
+
+class StopForward(Exception):
+    pass
+
+
+class Tape:
+    """Reverse-mode tape over token matrices.  Gradients are bf16 matrices keyed by tensor identity."""
+
+    def __init__(self):
+        self.fns = []
+        self.g = {}
+
+    def push(self, fn):
+        self.fns.append(fn)
+
+    def pop(self, t):
+        e = self.g.pop(id(t), None)
+        return None if e is None else e[1]
+
+    def peek(self, t):
+        e = self.g.get(id(t))
+        return None if e is None else e[1]
+
+    def accumulate(self, t, g):
+        e = self.g.get(id(t))
+        if e is None:
+            self.g[id(t)] = (t, g)
+        else:
+            ops.add(e[1], g, out=e[1])
+
+    def target(self, t):
+        """Buffer that receives d(t) and whether the producer must accumulate into it."""
+        e = self.g.get(id(t))
+        if e is not None:
+            return e[1], True
+        buf = torch.empty((t.shape[0], t.shape[1]), dtype=torch.bfloat16, device=t.device)
+        self.g[id(t)] = (t, buf)
+        return buf, False
+
+    def backward(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns = []
+
+
+@dataclass
+class Geom:
+    B: int
+    F: int
+    H: int
+    W: int
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    @property
+    def rows(self):
+        return self.B * self.F * self.H * self.W
+
+
+class TextCache:
+    """Per cross-attention layer [B*77, 2C] key/value projections of the prompt embeddings."""
+
+    def __init__(self, tokens, kv, B, ntext):
+        self.tokens = tokens  # [B*ntext, cross_dim] bf16
+        self.kv = kv
+        self.B = B
+        self.ntext = ntext
+
+
+class HipUNet3D:
+    def __init__(self, cfg: UNetConfig, state_dict, device="cuda"):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.w = {}
+        self.alpha = {}
+        self._dgrad = {}
+        self._pack(state_dict)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, sd):
+        dev = self.dev
+        w = self.w
+        for name, t in sd.items():
+            t = t.detach().to(torch.float32)
+            if t.dim() == 0:
+                self.alpha[name] = math.tanh(float(t))
+            elif t.dim() == 4:
+                if t.shape[2] == 3:
+                    if t.shape[1] % 8:  # conv_in: pad the 4 latent channels to 8
+                        pad = 8 - t.shape[1] % 8
+                        t = torch.cat([t, torch.zeros(t.shape[0], pad, 3, 3)], 1)
+                    w[name] = pack_conv3x3(t).to(dev)
+                else:
+                    w[name] = t.reshape(t.shape[0], t.shape[1]).to(torch.bfloat16).contiguous().to(dev)
+            elif t.dim() == 5:
+                w[name] = pack_tconv3(t).to(dev)
+            elif t.dim() == 2:
+                w[name] = t.to(torch.bfloat16).contiguous().to(dev)
+            else:
+                w[name] = t.contiguous().to(dev)  # norm affine / bias / null features stay fp32
+        # derived layouts
+        for name in [n for n in list(w.keys()) if n.endswith(".to_q.weight")]:
+            p = name[: -len(".to_q.weight")]
+            is_cross = ".attentions." in p and p.endswith(".attn2")
+            if is_cross:
+                w[p + ".to_kv.weight"] = torch.cat([w.pop(p + ".to_k.weight"), w.pop(p + ".to_v.weight")], 0).contiguous()
+            else:
+                w[p + ".to_qkv.weight"] = torch.cat([w.pop(p + ".to_q.weight"), w.pop(p + ".to_k.weight"), w.pop(p + ".to_v.weight")], 0).contiguous()
+        for name in [n for n in list(w.keys()) if n.endswith(".ff.net.0.proj.weight")]:
+            p = name[: -len(".weight")]
+            w[p + ".weight"], w[p + ".bias"] = interleave_geglu(w[p + ".weight"], w[p + ".bias"])
+        self.cross_layers = sorted(n[: -len(".to_kv.weight")] for n in w if n.endswith(".to_kv.weight"))
+
+    def wt(self, name, kind="linear"):
+        """Lazily built input-gradient layout of a packed weight (kept resident: 288 GB of HBM)."""
+        key = (name, kind)
+        t = self._dgrad.get(key)
+        if t is None:
+            W = self.w[name]
+            if kind == "linear":
+                t = W.t().contiguous()
+            elif kind == "conv":  # [cout, 9*cin] -> [cin, 9*cout], taps flipped
+                co = W.shape[0]
+                ci = W.shape[1] // 9
+                t = W.reshape(co, 3, 3, ci).flip(1, 2).permute(3, 1, 2, 0).reshape(ci, 9 * co).contiguous()
+            elif kind == "conv_t2":
+                co = W.shape[0]
+                ci = W.shape[1] // 9
+                t = W.reshape(co, 3, 3, ci).permute(3, 1, 2, 0).reshape(ci, 9 * co).contiguous()
+            elif kind == "tconv":
+                co = W.shape[0]
+                ci = W.shape[1] // 3
+                t = W.reshape(co, 3, ci).flip(1).permute(2, 1, 0).reshape(ci, 3 * co).contiguous()
+            else:
+                raise ValueError(kind)
+            self._dgrad[key] = t
+        return t
+
+    # ------------------------------------------------------------------ text
+    def encode_text(self, ehs):
+        """ehs: [B, 77, cross_dim] (any float dtype) -> TextCache with K|V of every cross-attention layer."""
+        B, nt, dc = ehs.shape
+        x = ehs.reshape(B * nt, dc).to(self.dev, torch.bfloat16).contiguous()
+        kv = {p: ops.gemm(x, self.w[p + ".to_kv.weight"]) for p in self.cross_layers}
+        return TextCache(x, kv, B, nt)
+
+    # ------------------------------------------------------------------ primitive ops with tape hooks
+    def _linear(self, x, name, *, tape, res=None, bias=True, x2=None, alpha=1.0, act=ops.ACT_NONE, out_fp32=False):
+        W = self.w[name + ".weight"]
+        b = self.w.get(name + ".bias") if bias else None
+        out = ops.gemm(x, W, a2=x2, bias=b, res=res, alpha=alpha, act=act, out_fp32=out_fp32)
+        if tape is not None:
+            assert act == ops.ACT_NONE and not out_fp32
+
+            def bw():
+                dy = tape.pop(out)
+                if dy is None:
+                    return
+                Wt = self.wt(name + ".weight")
+                if x2 is None:
+                    buf, acc = tape.target(x)
+                    ops.gemm(dy, Wt, out=buf, accumulate=acc, alpha=alpha)
+                else:
+                    tmp = ops.gemm(dy, Wt, alpha=alpha)
+                    c1 = x.shape[1]
+                    tape.accumulate(x, tmp[:, :c1])
+                    tape.accumulate(x2, tmp[:, c1:])
+                if res is not None:
+                    tape.accumulate(res, dy)
+            tape.push(bw)
+        return out
+
+    def _conv3x3(self, x, name, g_in: Geom, *, tape, stride=1, upsample=0, res=None, rowbias=None, x2=None, out_fp32=False):
+        W = self.w[name + ".weight"]
+        hin, win = (g_in.H * 2, g_in.W * 2) if upsample else (g_in.H, g_in.W)
+        hout, wout = ((hin - 1) // 2 + 1, (win - 1) // 2 + 1) if stride == 2 else (hin, win)
+        geo = ops.ConvGeom(hin, win, hout, wout, stride, upsample)
+        rps = g_in.F * hout * wout
+        out = ops.gemm(x, W, a2=x2, bias=self.w[name + ".bias"], rowbias=rowbias, rows_per_sample=rps if rowbias is not None else 0,
+                       res=res, mode=ops.A_CONV3X3, conv=geo, out_fp32=out_fp32)
+        if tape is not None:
+            assert x2 is None and not out_fp32
+
+            def bw():
+                dy = tape.pop(out)
+                if dy is None:
+                    return
+                nimg = g_in.B * g_in.F
+                if stride == 2:
+                    buf, acc = tape.target(x)
+                    ops.gemm(dy, self.wt(name + ".weight", "conv_t2"), out=buf, accumulate=acc, mode=ops.A_CONV3X3_T2,
+                             conv=ops.ConvGeom(hout, wout, hin, win), m=nimg * hin * win)
+                elif upsample:
+                    big = ops.gemm(dy, self.wt(name + ".weight", "conv"), mode=ops.A_CONV3X3, conv=ops.ConvGeom(hin, win, hin, win))
+                    buf, acc = tape.target(x)
+                    ops.upsample2x_bwd(big, nimg, g_in.H, g_in.W, x.shape[1], dx=buf, accumulate=acc)
+                else:
+                    buf, acc = tape.target(x)
+                    ops.gemm(dy, self.wt(name + ".weight", "conv"), out=buf, accumulate=acc, mode=ops.A_CONV3X3, conv=ops.ConvGeom(hin, win, hin, win))
+                if res is not None:
+                    tape.accumulate(res, dy)
+            tape.push(bw)
+        return out, Geom(g_in.B, g_in.F, hout, wout)
+
+    def _tconv(self, x, name, g: Geom, *, tape, res=None):
+        out = ops.gemm(x, self.w[name + ".weight"], bias=self.w[name + ".bias"], res=res, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
+        if tape is not None:
+            def bw():
+                dy = tape.pop(out)
+                if dy is None:
+                    return
+                buf, acc = tape.target(x)
+                ops.gemm(dy, self.wt(name + ".weight", "tconv"), out=buf, accumulate=acc, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
+                if res is not None:
+                    tape.accumulate(res, dy)
+            tape.push(bw)
+        return out
+
+    def _groupnorm(self, x, name, rps, *, tape, eps, silu, x2=None):
+        gamma, beta = self.w[name + ".weight"], self.w[name + ".bias"]
+        G = self.cfg.norm_num_groups
+        ss, mr = ops.groupnorm_stats(x, gamma, beta, rps, groups=G, eps=eps, x2=x2)
+        out = ops.groupnorm_apply(x, ss, rps, silu=silu, x2=x2)
+        if tape is not None:
+            def bw():
+                dy = tape.pop(out)
+                if dy is None:
+                    return
+                if x2 is None:
+                    buf, acc = tape.target(x)
+                    ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, groups=G, silu=silu, dx1=buf, accumulate=acc)
+                else:
+                    d1, d2 = ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, groups=G, silu=silu, x2=x2)
+                    tape.accumulate(x, d1)
+                    tape.accumulate(x2, d2)
+            tape.push(bw)
+        return out
+
+    def _layernorm(self, x, name, *, tape):
+        gamma, beta = self.w[name + ".weight"], self.w[name + ".bias"]
+        if tape is None:
+            return ops.layernorm(x, gamma, beta)
+        out, mr = ops.layernorm(x, gamma, beta, return_stats=True)
+
+        def bw():
+            dy = tape.pop(out)
+            if dy is None:
+                return
+            buf, acc = tape.target(x)
+            ops.layernorm_bwd(x, dy, gamma, mr, dx=buf, accumulate=acc)
+        tape.push(bw)
+        return out
+
+    def _self_attention(self, x, name, heads, *, samples, seq, rowmap, tape, x_extra=None, extra_map=None, seq_extra=0):
+        """LN'd tokens -> fused QKV GEMM -> flash attention.  x_extra: second key/value segment (GLIGEN objs)."""
+        C = heads * 64
+        qkv = ops.gemm(x, self.w[name + ".to_qkv.weight"])
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        o = torch.empty((x.shape[0], C), dtype=torch.bfloat16, device=x.device)
+        kw = dict(samples=samples, heads=heads, sq=seq, skv=seq, qmap=rowmap, kvmap=rowmap, scale=0.125)
+        if x_extra is not None:
+            assert tape is None, "the guidance pass runs without GLIGEN conditioning (reference: models/pipelines.py:66-72)"
+            qkv2 = ops.gemm(x_extra, self.w[name + ".to_qkv.weight"])
+            kw.update(k2=qkv2[:, C:2 * C], v2=qkv2[:, 2 * C:], skv2=seq_extra, kv2map=extra_map)
+        lse = torch.empty((samples, heads, seq), dtype=torch.float32, device=x.device) if tape is not None else None
+        ops.attention_fwd(q, k, v, o, lse=lse, **kw)
+        if tape is not None:
+            def bw():
+                do = tape.pop(o)
+                if do is None:
+                    return
+                dqkv = torch.empty_like(qkv)
+                ops.attention_bwd(q, k, v, o, lse, do, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], **kw)
+                buf, acc = tape.target(x)
+                ops.gemm(dqkv, self.wt(name + ".to_qkv.weight"), out=buf, accumulate=acc)
+            tape.push(bw)
+        return o
+
+    def _cross_attention(self, x, name, heads, text: TextCache, g: Geom, *, tape, key=None, collect=None):
+        C = heads * 64
+        q = self._linear(x, name + ".to_q", tape=tape, bias=False)
+        kv = text.kv[name]
+        k, v = kv[:, :C], kv[:, C:]
+        if collect is not None and key in collect["keys"]:
+            collect["q"][key] = (q, k, heads, g)
+            if key == collect.get("stop_after"):
+                raise StopForward()
+        o = torch.empty((x.shape[0], C), dtype=torch.bfloat16, device=x.device)
+        samples = g.B * g.F
+        kw = dict(samples=samples, heads=heads, sq=g.HW, skv=text.ntext, qmap=ops.RowMap(1, g.HW, 0, 1),
+                  kvmap=ops.RowMap(g.F, text.ntext, 0, 1), scale=0.125)
+        lse = torch.empty((samples, heads, g.HW), dtype=torch.float32, device=x.device) if tape is not None else None
+        ops.attention_fwd(q, k, v, o, lse=lse, **kw)
+        if tape is not None:
+            def bw():
+                do = tape.pop(o)
+                if do is None:
+                    return
+                buf, acc = tape.target(q)
+                if acc:  # q already carries the loss gradient: add the attention-path gradient to it
+                    dq = torch.empty_like(q)
+                    ops.attention_bwd(q, k, v, o, lse, do, dq, None, None, **kw)
+                    ops.add(buf, dq, out=buf)
+                else:
+                    ops.attention_bwd(q, k, v, o, lse, do, buf, None, None, **kw)
+            tape.push(bw)
+        return o
+
+    def _feed_forward(self, x, name, res, *, tape, alpha=1.0):
+        if tape is None:
+            h = self._linear(x, name + ".net.0.proj", tape=None, act=ops.ACT_GEGLU)
+        else:
+            pre = self._linear(x, name + ".net.0.proj", tape=tape)
+            h = ops.geglu_fwd(pre)
+
+            def bw():
+                dh = tape.pop(h)
+                if dh is None:
+                    return
+                tape.accumulate(pre, ops.geglu_bwd(pre, dh))
+            tape.push(bw)
+        return self._linear(h, name + ".net.2", tape=tape, res=res, alpha=alpha)
+
+    # ------------------------------------------------------------------ composite blocks
+    def _transformer_block(self, hs, name, heads, *, tape, spatial, g: Geom, text=None, objs=None, key=None, collect=None):
+        if spatial:
+            samples, seq, rmap = g.B * g.F, g.HW, ops.RowMap(1, g.HW, 0, 1)
+        else:
+            samples, seq, rmap = g.B * g.HW, g.F, ops.RowMap(g.HW, g.F * g.HW, 1, g.HW)
+        n1 = self._layernorm(hs, name + ".norm1", tape=tape)
+        o = self._self_attention(n1, name + ".attn1", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
+        hs = self._linear(o, name + ".attn1.to_out.0", tape=tape, res=hs)
+        if objs is not None and (name + ".fuser.linear.weight") in self.w:
+            hs = self._fuser(hs, name + ".fuser", heads, objs, g)
+        n2 = self._layernorm(hs, name + ".norm2", tape=tape)
+        if spatial:
+            o = self._cross_attention(n2, name + ".attn2", heads, text, g, tape=tape, key=key, collect=collect)
+        else:
+            o = self._self_attention(n2, name + ".attn2", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
+        hs = self._linear(o, name + ".attn2.to_out.0", tape=tape, res=hs)
+        n3 = self._layernorm(hs, name + ".norm3", tape=tape)
+        return self._feed_forward(n3, name + ".ff", hs, tape=tape)
+
+    def _fuser(self, hs, name, heads, objs, g: Geom):
+        """GatedSelfAttentionDense (models/attention.py:44-60); objs: [B*F*30, cross_dim] bf16."""
+        nobj = objs.shape[0] // (g.B * g.F)
+        o_tok = self._linear(objs, name + ".linear", tape=None)
+        n_vis = self._layernorm(hs, name + ".norm1", tape=None)
+        n_obj = self._layernorm(o_tok, name + ".norm1", tape=None)
+        o = self._self_attention(n_vis, name + ".attn", heads, samples=g.B * g.F, seq=g.HW, rowmap=ops.RowMap(1, g.HW, 0, 1), tape=None,
+                                 x_extra=n_obj, extra_map=ops.RowMap(1, nobj, 0, 1), seq_extra=nobj)
+        hs = self._linear(o, name + ".attn.to_out.0", tape=None, res=hs, alpha=self.alpha[name + ".alpha_attn"])
+        n2 = self._layernorm(hs, name + ".norm2", tape=None)
+        return self._feed_forward(n2, name + ".ff", hs, tape=None, alpha=self.alpha[name + ".alpha_dense"])
+
+    def _transformer2d(self, x, name, heads, g: Geom, text, *, tape, objs=None, key=None, collect=None):
+        h = self._groupnorm(x, name + ".norm", g.HW, tape=tape, eps=1e-6, silu=False)
+        hs = self._linear(h, name + ".proj_in", tape=tape)
+        hs = self._transformer_block(hs, name + ".transformer_blocks.0", heads, tape=tape, spatial=True, g=g, text=text, objs=objs, key=key, collect=collect)
+        return self._linear(hs, name + ".proj_out", tape=tape, res=x)
+
+    def _transformer_temporal(self, x, name, heads, g: Geom, *, tape):
+        h = self._groupnorm(x, name + ".norm", g.F * g.HW, tape=tape, eps=1e-6, silu=False)
+        hs = self._linear(h, name + ".proj_in", tape=tape)
+        hs = self._transformer_block(hs, name + ".transformer_blocks.0", heads, tape=tape, spatial=False, g=g)
+        return self._linear(hs, name + ".proj_out", tape=tape, res=x)
+
+    def _resnet(self, x, name, g: Geom, temb_act, *, tape, skip=None):
+        eps = self.cfg.norm_eps
+        h = self._groupnorm(x, name + ".norm1", g.HW, tape=tape, eps=eps, silu=True, x2=skip)
+        rb = ops.gemm(temb_act, self.w[name + ".time_emb_proj.weight"], bias=self.w[name + ".time_emb_proj.bias"], out_fp32=True)
+        h, _ = self._conv3x3(h, name + ".conv1", g, tape=tape, rowbias=rb)
+        h = self._groupnorm(h, name + ".norm2", g.HW, tape=tape, eps=eps, silu=True)
+        if (name + ".conv_shortcut.weight") in self.w:
+            sc = self._linear(x, name + ".conv_shortcut", tape=tape, x2=skip)
+        else:
+            assert skip is None
+            sc = x
+        out, _ = self._conv3x3(h, name + ".conv2", g, tape=tape, res=sc)
+        return out
+
+    def _temporal_conv(self, x, name, g: Geom, *, tape):
+        rps = g.F * g.HW
+        h = x
+        for k, ci in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
+            h = self._groupnorm(h, f"{name}.{k}.0", rps, tape=tape, eps=1e-5, silu=True)
+            h = self._tconv(h, f"{name}.{k}.{ci}", g, tape=tape, res=x if k == "conv4" else None)
+        return h
+
+    def position_net(self, boxes, masks, positive_embeddings):
+        """PositionNet (unet_3d_condition.py:119-179) on [N,30,·] tensors -> objs token matrix [N*30, cross_dim] bf16.
+        The Fourier features / null-feature blend are tiny host-side tensor prep; the MLP runs on the GEMM kernel."""
+        m = masks.to(self.dev, torch.float32).unsqueeze(-1)
+        boxes = boxes.to(self.dev, torch.float32)
+        freq = 100.0 ** (torch.arange(8, dtype=torch.float32, device=self.dev) / 8)
+        e = freq[None, None, None] * boxes.unsqueeze(-1)
+        xyxy = torch.stack((e.sin(), e.cos()), -1).permute(0, 1, 3, 4, 2).reshape(*boxes.shape[:2], -1)
+        xyxy = xyxy * m + (1 - m) * self.w["position_net.null_position_feature"].view(1, 1, -1)
+        pos = positive_embeddings.to(self.dev, torch.float32) * m + (1 - m) * self.w["position_net.null_positive_feature"].view(1, 1, -1)
+        h = torch.cat([pos, xyxy], -1).reshape(-1, pos.shape[-1] + xyxy.shape[-1]).to(torch.bfloat16).contiguous()
+        h = ops.silu(self._linear(h, "position_net.linears.0", tape=None))
+        h = ops.silu(self._linear(h, "position_net.linears.2", tape=None))
+        return self._linear(h, "position_net.linears.4", tape=None)
+
+    # ------------------------------------------------------------------ whole model
+    def forward(self, sample, timestep, encoder_hidden_states=None, *, text: TextCache = None, gligen=None, fuser_enabled=True,
+                tape: Tape = None, collect=None):
+        """sample (B,4,F,h,w) fp32 CUDA -> noise prediction (B,4,F,h,w) fp32.
+
+        collect = {"keys": [...], "q": {}, "stop_after": key}: store (q, k_text, heads, geom) of the listed
+        cross-attention layers (attn_key tuples as in the reference) and optionally stop there.
+        Returns None when stopped early.
+        """
+        cfg = self.cfg
+        boc = cfg.block_out_channels
+        dh = cfg.attention_head_dim
+        assert dh == 64, "kernels are specialised for attention_head_dim 64"
+        sample = sample.to(self.dev, torch.float32).contiguous()
+        B, Cin, Fr, H, W = sample.shape
+        g = Geom(B, Fr, H, W)
+        if text is None:
+            text = self.encode_text(encoder_hidden_states)
+        assert text.B == B
+        if torch.is_tensor(timestep):
+            t = timestep.to(self.dev, torch.float32).reshape(-1).expand(B).contiguous()
+        else:
+            t = torch.full((B,), float(timestep), dtype=torch.float32, device=self.dev)
+        temb = ops.timestep_embedding(t, boc[0])
+        emb = self._linear(ops.silu(self._linear(temb, "time_embedding.linear_1", tape=None)), "time_embedding.linear_2", tape=None)
+        temb_act = ops.silu(emb)  # every ResnetBlock2D applies SiLU to temb first
+
+        tokens = ops.latents_to_tokens(sample, cpad=8)
+        x, _ = self._conv3x3(tokens, "conv_in", g, tape=tape)
+        x = self._transformer_temporal(x, "transformer_in", cfg.transformer_in_heads, g, tape=tape)
+        objs = None
+        if gligen is not None and fuser_enabled and cfg.gated:
+            objs = self.position_net(gligen["boxes"], gligen["masks"], gligen["positive_embeddings"])
+
+        def layer(prefix, j, key, x, g, has_attn, c, skip=None):
+            x = self._resnet(x, f"{prefix}.resnets.{j}", g, temb_act, tape=tape, skip=skip)
+            x = self._temporal_conv(x, f"{prefix}.temp_convs.{j}", g, tape=tape)
+            if has_attn:
+                x = self._transformer2d(x, f"{prefix}.attentions.{j}", c // dh, g, text, tape=tape, objs=objs, key=key, collect=collect)
+                x = self._transformer_temporal(x, f"{prefix}.temp_attentions.{j}", c // dh, g, tape=tape)
+            return x
+
+        try:
+            skips = [(x, g)]
+            for i, btype in enumerate(cfg.down_block_types):
+                c = boc[i]
+                for j in range(cfg.layers_per_block):
+                    x = layer(f"down_blocks.{i}", j, ("down", i, j, 0), x, g, btype == "CrossAttnDownBlock3D", c)
+                    skips.append((x, g))
+                if i != len(boc) - 1:
+                    x, g = self._conv3x3(x, f"down_blocks.{i}.downsamplers.0.conv", g, tape=tape, stride=2)
+                    skips.append((x, g))
+            c = boc[-1]
+            x = self._resnet(x, "mid_block.resnets.0", g, temb_act, tape=tape)
+            x = self._temporal_conv(x, "mid_block.temp_convs.0", g, tape=tape)
+            x = self._transformer2d(x, "mid_block.attentions.0", c // dh, g, text, tape=tape, objs=objs, key=("mid", 0, 0, 0), collect=collect)
+            x = self._transformer_temporal(x, "mid_block.temp_attentions.0", c // dh, g, tape=tape)
+            x = self._resnet(x, "mid_block.resnets.1", g, temb_act, tape=tape)
+            x = self._temporal_conv(x, "mid_block.temp_convs.1", g, tape=tape)
+            rev = list(reversed(boc))
+            for i, btype in enumerate(cfg.up_block_types):
+                c = rev[i]
+                for j in range(cfg.layers_per_block + 1):
+                    skip, gs = skips.pop()
+                    assert (gs.H, gs.W) == (g.H, g.W)
+                    x = layer(f"up_blocks.{i}", j, ("up", i, j, 0), x, g, btype == "CrossAttnUpBlock3D", c, skip=skip)
+                if i != len(boc) - 1:
+                    gt = skips[-1][1]
+                    assert (gt.H, gt.W) == (2 * g.H, 2 * g.W), "latent H,W must be divisible by 8 (nearest x2 upsampling only)"
+                    x, g = self._conv3x3(x, f"up_blocks.{i}.upsamplers.0.conv", g, tape=tape, upsample=1)
+        except StopForward:
+            self._tokens_in = tokens
+            return None
+        self._tokens_in = tokens
+        h = self._groupnorm(x, "conv_norm_out", g.HW, tape=tape, eps=cfg.norm_eps, silu=True)
+        out32, _ = self._conv3x3(h, "conv_out", g, tape=None, out_fp32=True)
+        return ops.tokens_to_latents(out32, B, cfg.out_channels, Fr, H, W)
+
+    def input_gradient(self, tape: Tape, g: Geom, scale=1.0):
+        """After tape.backward(): gradient w.r.t. the (B,4,F,h,w) latents."""
+        dtok = tape.pop(self._tokens_in)
+        assert dtok is not None, "no gradient reached the latents"
+        return ops.tokens_grad_to_latents(dtok, g.B, self.cfg.in_channels, g.F, g.H, g.W, scale=scale)
