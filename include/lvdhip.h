@@ -222,16 +222,17 @@ int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream);
 
 typedef struct {
   const float* probs;                   /* [frames, heads, ntok, P] */
-  float* dprobs;                        /* out, same shape (zero where no gradient) */
+  float* dprobs;                        /* out, same shape: d(loss)/d(probs), already scaled by grad_scale */
   int32_t frames, heads, P, ntok, H, W; /* P = H*W */
   const int32_t* tok_obj;               /* [ntok] object index of each token column */
-  const int32_t* boxes;                 /* [nobj, frames, 4] integer (x_min,y_min,x_max,y_max) at (H,W) */
-  const float* tok_weight;              /* [ntok] = 1/|T_o| */
+  const int32_t* boxes;                 /* [nobj, frames, 6] = (x_min,y_min,x_max,y_max) at (H,W) via scale_proportion
+                                           (utils/utils.py:82-103), then k_fg, k_bg (utils/guidance.py:328-337) */
+  const float* tok_weight;              /* [ntok] = 1/|T_o| (utils/guidance.py:524) */
   int32_t nobj;
-  float fg_top_p, bg_top_p, fg_weight, bg_weight, com_loss_scale;
-  float grad_scale;                     /* loss_scale / (nobj * nkeys) */
-  float* loss_partial;                  /* out [frames*heads*ntok] un-scaled partial sums (+ com in slot) */
-  float* com_ws;                        /* workspace [frames, heads, ntok, 4] (sum, com_y, com_x, pad) */
+  float fg_weight, bg_weight, com_loss_scale;
+  float grad_scale;                     /* loss_scale / (nobj * nkeys)  (utils/guidance.py:569-572, pipelines.py:101-112) */
+  float* loss_partial;                  /* out [frames*heads*ntok]: per-(frame,head,token) loss terms, un-scaled */
+  float* com_ws;                        /* workspace [frames, heads, ntok, 4] = (sum, com_y, com_x, -) */
 } lvd_ca_select_params;
 int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream);
 

@@ -1,5 +1,373 @@
-// guidance_loss.hip — placeholder, replaced below in this round.
+// guidance_loss.hip — fused cross-attention-energy guidance loss, forward + backward, for gfx950.
+//
+// Reference path being replaced (per guidance key and iteration):
+//   AttnProcessor slow path materialises softmax(scale·QK^T) as (frames·heads, HW, 77) fp16, clones it into
+//   save_attn_to_dict (models/attention_processor.py:515-586); utils/guidance.py:231-524 then loops over
+//   objects × frames × tokens in Python launching mask fills, column gathers, two top-k and reductions each;
+//   autograd later walks all of it backwards (models/pipelines.py:120).
+// Here: the probability maps are never materialised.  Only the object-token columns are kept (fp32,
+// [frames, heads, ntok, P]) and everything is three launches per key:
+//   1. ca_probs  : MFMA K·Q^T over the 77 text keys -> row LSE + probabilities of the object tokens
+//   2. ca_select : per (frame, head, token) block: exact top-k_fg / top-k_bg by radix select (ties broken by
+//                  lowest index), centre-of-mass + velocity terms, loss partial and d(loss)/d(prob)
+//   3. ca_dq     : softmax backward over the 77 keys (only the token columns carry gradient) and
+//                  dQ = scale · dS · K with K^T staged through LDS — HBM traffic = read Q + write dQ.
+// All loss arithmetic is fp32 (the reference's mask is fp32, so A·mask promotes: utils/guidance.py:239,339-353).
 #include "common.h"
-extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) { (void)p; (void)stream; LVD_CHECK(false, "ca_probs: not implemented yet"); }
-extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) { (void)p; (void)stream; LVD_CHECK(false, "ca_select: not implemented yet"); }
-extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) { (void)p; (void)stream; LVD_CHECK(false, "ca_dq: not implemented yet"); }
+
+namespace {
+
+constexpr int TP = 18;
+constexpr int MAXTOK = 16;
+
+LVD_DEV void stage_transposed(uint32_t* lds, const lvd_bf16* r0, const lvd_bf16* r1, int vj, int vdc) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    int d0 = vdc * 8 + 32 * half;
+    uint4 a = ldg16(r0 + d0);
+    uint4 b = ldg16(r1 + d0);
+    uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lds[(d0 + 2 * e) * TP + vj] = (aw[e] & 0xffffu) | (bw[e] << 16);
+      lds[(d0 + 2 * e + 1) * TP + vj] = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
+    }
+  }
+}
+LVD_DEV bf16x8 frag_transposed(const uint32_t* lds, int d, int ks2, int hi) {
+  const uint32_t* r = lds + d * TP + ks2 * 8 + 2 * hi;
+  uint2 lo = *reinterpret_cast<const uint2*>(r);
+  uint2 h2 = *reinterpret_cast<const uint2*>(r + 4);
+  return as_bf16x8(make_uint4(lo.x, lo.y, h2.x, h2.y));
+}
+LVD_DEV float dot8(uint4 a, uint4 b) {
+  return bflo(a.x) * bflo(b.x) + bfhi(a.x) * bfhi(b.x) + bflo(a.y) * bflo(b.y) + bfhi(a.y) * bfhi(b.y) +
+         bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
+}
+
+// ------------------------------------------------------------------------------------ 1. probs
+// grid (frames * ceil(P/32), heads), one wave per 32-query tile
+__global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params p) {
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.P + 31) >> 5;
+  const int f = blockIdx.x / nqt, qt = blockIdx.x - f * nqt, h = blockIdx.y;
+  const int qi = qt * 32 + l31;
+  const int qic = min(qi, p.P - 1);
+  const lvd_bf16* qp = p.q + ((long)f * p.P + qic) * p.ldq + h * 64 + hi * 8;
+  uint4 qraw[4];
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { qraw[ks] = ldg16(qp + ks * 16); qf[ks] = as_bf16x8(qraw[ks]); }
+  const float sc = p.scale * 1.4426950408889634f;
+  float m = -1e30f, lsum = 0.f;
+  for (int kt = 0; kt * 32 < p.ntext; ++kt) {
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+    int kk = min(kt * 32 + l31, p.ntext - 1);
+    const lvd_bf16* kp = p.k + (long)kk * p.ldk + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ldg16(kp + ks * 16)), qf[ks], st, 0, 0, 0);
+    float v[16], tmax = -1e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      v[e] = kidx < p.ntext ? st[e] * sc : -1e30f;
+      tmax = fmaxf(tmax, v[e]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    float mn = fmaxf(m, tmax), rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rs += exp2f(v[e] - mn);
+    lsum = lsum * exp2f(m - mn) + rs;
+    m = mn;
+  }
+  float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  float lse2 = m + log2f(ltot);
+  const long row = ((long)f * p.heads + h);
+  if (hi == 0 && qi < p.P) p.lse[row * p.P + qi] = lse2 * 0.6931471805599453f;
+  for (int t = 0; t < p.ntok; ++t) {
+    const lvd_bf16* kp = p.k + (long)p.tok_ids[t] * p.ldk + h * 64 + hi * 8;
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s += dot8(qraw[ks], ldg16(kp + ks * 16));
+    s += __shfl_xor(s, 32, 64);
+    if (hi == 0 && qi < p.P) p.probs[(row * p.ntok + t) * p.P + qi] = exp2f(s * sc - lse2);
+  }
+}
+
+// ------------------------------------------------------------------------------------ 2a. centre of mass
+// grid frames*heads*ntok, block 256: com_ws[.,4] = (sum A, com_y, com_x, 0)
+__global__ void ca_com_kernel(const lvd_ca_select_params p) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.x;
+  const float* A = p.probs + (long)b * p.P;
+  float s = 0.f, sy = 0.f, sx = 0.f;
+  for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
+    float a = A[i];
+    int y = i / p.W, x = i - y * p.W;
+    s += a; sy += a * (float)y; sx += a * (float)x;
+  }
+  s = wave_sum(s); sy = wave_sum(sy); sx = wave_sum(sx);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = s; red[1][w] = sy; red[2][w] = sx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    float Y = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    float X = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    p.com_ws[(long)b * 4 + 0] = S;
+    p.com_ws[(long)b * 4 + 1] = Y / S;
+    p.com_ws[(long)b * 4 + 2] = X / S;
+    p.com_ws[(long)b * 4 + 3] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------ 2b. select
+// Exact k-th largest of 44-bit keys (value bits << 12 | (4095 - index)) among the entries with flag==want.
+// Returns the key of the k-th largest; entries with key >= result are the top-k set.
+LVD_DEV unsigned long long radix_select(const float* vals, const unsigned char* flag, unsigned char want, int n, int k,
+                                        unsigned int* hist, unsigned long long* sh) {
+  unsigned long long prefix = 0, maskbits = 0;
+  int need = k;
+  for (int pass = 5; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      if (flag[i] != want) continue;
+      unsigned long long key = ((unsigned long long)__float_as_uint(vals[i]) << 12) | (unsigned)(4095 - i);
+      if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int b = 255, rem = need;
+      for (; b > 0; --b) {
+        int c = (int)hist[b];
+        if (c >= rem) break;
+        rem -= c;
+      }
+      sh[0] = (unsigned long long)b;
+      sh[1] = (unsigned long long)rem;
+    }
+    __syncthreads();
+    prefix |= sh[0] << (8 * pass);
+    maskbits |= 0xffull << (8 * pass);
+    need = (int)sh[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_params p) {
+  extern __shared__ unsigned char smem[];
+  float* vals = reinterpret_cast<float*>(smem);                         // [P]
+  unsigned char* flag = smem + (size_t)p.P * 4;                         // [P] 1 = inside the box
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long sh[2];
+  __shared__ float red[8];
+
+  const int b = blockIdx.x;
+  const int t = b % p.ntok;
+  const int fh = b / p.ntok;
+  const int h = fh % p.heads, f = fh / p.heads;
+  const int obj = p.tok_obj[t];
+  const int* bx = p.boxes + ((long)obj * p.frames + f) * 6;
+  const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3], kfg = bx[4], kbg = bx[5];
+  const int nmask = max(0, x1 - x0) * max(0, y1 - y0);
+  const float* A = p.probs + (long)b * p.P;
+  float* dA = p.dprobs + (long)b * p.P;
+  const float wt = p.tok_weight[t];
+  const float c = p.grad_scale * wt;
+
+  for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
+    int y = i / p.W, x = i - y * p.W;
+    vals[i] = A[i];
+    flag[i] = (y >= y0 && y < y1 && x >= x0 && x < x1) ? 1 : 0;
+  }
+  __syncthreads();
+
+  unsigned long long thr_fg = ~0ull, thr_bg = ~0ull;  // "nothing selected"
+  if (nmask > 0) thr_fg = radix_select(vals, flag, 1, p.P, kfg, hist, sh);
+  if (p.P - nmask > 0) thr_bg = radix_select(vals, flag, 0, p.P, kbg, hist, sh);
+
+  // centre-of-mass gradient coefficients: dL/dA[p] = gy*(y - cy)/S + gx*(x - cx)/S  (+ same with the t1 roles)
+  float gy = 0.f, gx = 0.f, cy = 0.f, cx = 0.f, S = 1.f, com_loss = 0.f;
+  if (p.com_loss_scale > 0.f && nmask > 0) {
+    const float* cw = p.com_ws + (long)b * 4;
+    S = cw[0]; cy = cw[1]; cx = cw[2];
+    float my = 0.5f * (float)(y0 + y1 - 1), mx = 0.5f * (float)(x0 + x1 - 1);
+    float ey = cy - my, ex = cx - mx;
+    const float kh = p.com_loss_scale / (float)p.heads;
+    com_loss += kh * (ey * ey + ex * ex);
+    gy += 2.f * kh * ey; gx += 2.f * kh * ex;
+    // velocity term with the next frame (utils/guidance.py:489-522); f1 = min(f+1, F-1)
+    if (f + 1 < p.frames) {
+      const int* b1 = p.boxes + ((long)obj * p.frames + f + 1) * 6;
+      int n1 = max(0, b1[2] - b1[0]) * max(0, b1[3] - b1[1]);
+      if (n1 > 0) {
+        const float* c1 = p.com_ws + ((long)b + (long)p.heads * p.ntok) * 4;
+        float my1 = 0.5f * (float)(b1[1] + b1[3] - 1), mx1 = 0.5f * (float)(b1[0] + b1[2] - 1);
+        float vy = (c1[1] - cy) - (my1 - my), vx = (c1[2] - cx) - (mx1 - mx);
+        com_loss += kh * (vy * vy + vx * vx);
+        gy -= 2.f * kh * vy; gx -= 2.f * kh * vx;
+      }
+    }
+    // this frame acting as "t1" of the previous frame's velocity term
+    if (f >= 1) {
+      const int* b0 = p.boxes + ((long)obj * p.frames + f - 1) * 6;
+      int n0 = max(0, b0[2] - b0[0]) * max(0, b0[3] - b0[1]);
+      if (n0 > 0) {
+        const float* c0 = p.com_ws + ((long)b - (long)p.heads * p.ntok) * 4;
+        float my0 = 0.5f * (float)(b0[1] + b0[3] - 1), mx0 = 0.5f * (float)(b0[0] + b0[2] - 1);
+        float vy = (cy - c0[1]) - (my - my0), vx = (cx - c0[2]) - (mx - mx0);
+        gy += 2.f * kh * vy; gx += 2.f * kh * vx;
+      }
+    }
+  }
+
+  float sfg = 0.f, sbg = 0.f;
+  const float gfg = -p.fg_weight / (float)kfg, gbg = p.bg_weight / (float)kbg;
+  for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
+    float a = vals[i];
+    unsigned long long key = ((unsigned long long)__float_as_uint(a) << 12) | (unsigned)(4095 - i);
+    float g = 0.f;
+    if (flag[i]) {
+      if (key >= thr_fg) { sfg += a; g += gfg; }
+    } else {
+      if (key >= thr_bg) { sbg += a; g += gbg; }
+    }
+    if (gy != 0.f || gx != 0.f) {
+      int y = i / p.W, x = i - y * p.W;
+      g += (gy * ((float)y - cy) + gx * ((float)x - cx)) / S;
+    }
+    dA[i] = c * g;
+  }
+  sfg = wave_sum(sfg); sbg = wave_sum(sbg);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = sfg; red[4 + w] = sbg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tf = red[0] + red[1] + red[2] + red[3], tb = red[4] + red[5] + red[6] + red[7];
+    float loss = p.fg_weight * (1.f - tf / (float)kfg) + p.bg_weight * (tb / (float)kbg) + com_loss;
+    p.loss_partial[b] = wt * loss;
+  }
+}
+
+// ------------------------------------------------------------------------------------ 3. dQ
+__global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
+  __shared__ uint32_t kt_lds[64 * TP];
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.P + 31) >> 5;
+  const int f = blockIdx.x / nqt, qt = blockIdx.x - f * nqt, h = blockIdx.y;
+  const int qi = qt * 32 + l31;
+  const int qic = min(qi, p.P - 1);
+  const lvd_bf16* qp = p.q + ((long)f * p.P + qic) * p.ldq + h * 64 + hi * 8;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
+  const long row = ((long)f * p.heads + h);
+  const float lse2 = p.lse[row * p.P + qic] * 1.4426950408889634f;
+  const float sc = p.scale * 1.4426950408889634f;
+  // per-query token-column gradients and c = sum_t A_t dA_t
+  float da[MAXTOK];
+  int tk[MAXTOK];
+  float cq = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXTOK; ++t) {
+    da[t] = 0.f; tk[t] = -1;
+    if (t < p.ntok) {
+      long idx = (row * p.ntok + t) * p.P + qic;
+      da[t] = p.dprobs[idx];
+      tk[t] = p.tok_ids[t];
+      cq += p.probs[idx] * da[t];
+    }
+  }
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq0[e] = 0.f; dq1[e] = 0.f; }
+  const int vj = lane & 15, vdc = lane >> 4;
+  for (int kt = 0; kt * 32 < p.ntext; ++kt) {
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+    {
+      int kk = min(kt * 32 + l31, p.ntext - 1);
+      const lvd_bf16* kp = p.k + (long)kk * p.ldk + h * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ldg16(kp + ks * 16)), qf[ks], st, 0, 0, 0);
+    }
+    {
+      int k0 = min(kt * 32 + 2 * vj, p.ntext - 1), k1 = min(kt * 32 + 2 * vj + 1, p.ntext - 1);
+      stage_transposed(kt_lds, p.k + (long)k0 * p.ldk + h * 64, p.k + (long)k1 * p.ldk + h * 64, vj, vdc);
+    }
+    __syncthreads();
+    float ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      float pr = kidx < p.ntext ? exp2f(st[e] * sc - lse2) : 0.f;
+      float g = -cq;
+#pragma unroll
+      for (int t = 0; t < MAXTOK; ++t) g += (tk[t] == kidx) ? da[t] : 0.f;
+      ds[e] = pr * g;
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      uint4 w;
+      w.x = pack2bf(ds[ks2 * 8 + 0], ds[ks2 * 8 + 1]); w.y = pack2bf(ds[ks2 * 8 + 2], ds[ks2 * 8 + 3]);
+      w.z = pack2bf(ds[ks2 * 8 + 4], ds[ks2 * 8 + 5]); w.w = pack2bf(ds[ks2 * 8 + 6], ds[ks2 * 8 + 7]);
+      bf16x8 dsf = as_bf16x8(w);
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(kt_lds, l31, ks2, hi), dsf, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(kt_lds, 32 + l31, ks2, hi), dsf, dq1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (qi < p.P) {
+    lvd_bf16* op = p.dq + ((long)f * p.P + qi) * p.lddq + h * 64 + 4 * hi;
+    const float fs = p.scale;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      uint2 w0, w1;
+      w0.x = pack2bf(dq0[rq * 4 + 0] * fs, dq0[rq * 4 + 1] * fs); w0.y = pack2bf(dq0[rq * 4 + 2] * fs, dq0[rq * 4 + 3] * fs);
+      w1.x = pack2bf(dq1[rq * 4 + 0] * fs, dq1[rq * 4 + 1] * fs); w1.y = pack2bf(dq1[rq * 4 + 2] * fs, dq1[rq * 4 + 3] * fs);
+      stg8(op + 8 * rq, w0);
+      stg8(op + 32 + 8 * rq, w1);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) {
+  LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->lse, "ca_probs: null pointer");
+  LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_probs: ntok=%d outside 1..%d", p->ntok, MAXTOK);
+  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0, "ca_probs: leading dims");
+  dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
+  hipLaunchKernelGGL(ca_probs_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) {
+  LVD_CHECK(p && p->probs && p->dprobs && p->tok_obj && p->boxes && p->tok_weight && p->loss_partial && p->com_ws, "ca_select: null pointer");
+  LVD_CHECK(p->P == p->H * p->W && p->P <= 4096, "ca_select: P=%d must equal H*W and be <= 4096", p->P);
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = p->frames * p->heads * p->ntok;
+  if (p->com_loss_scale > 0.f) {
+    hipLaunchKernelGGL(ca_com_kernel, dim3(blocks), dim3(256), 0, s, *p);
+    LVD_LAUNCH_CHECK();
+  }
+  size_t smem = (size_t)p->P * 5 + 16;
+  hipLaunchKernelGGL(ca_select_kernel, dim3(blocks), dim3(256), smem, s, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) {
+  LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->dprobs && p->lse && p->dq, "ca_dq: null pointer");
+  LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_dq: ntok=%d outside 1..%d", p->ntok, MAXTOK);
+  dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
+  hipLaunchKernelGGL(ca_dq_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}

@@ -115,7 +115,7 @@ class HipUNet3D:
                 if t.shape[2] == 3:
                     if t.shape[1] % 8:  # conv_in: pad the 4 latent channels to 8
                         pad = 8 - t.shape[1] % 8
-                        t = torch.cat([t, torch.zeros(t.shape[0], pad, 3, 3)], 1)
+                        t = torch.cat([t, torch.zeros(t.shape[0], pad, 3, 3, device=t.device)], 1)
                     w[name] = pack_conv3x3(t).to(dev)
                 else:
                     w[name] = t.reshape(t.shape[0], t.shape[1]).to(torch.bfloat16).contiguous().to(dev)

@@ -1,0 +1,215 @@
+"""Backward guidance on the HIP engine: drop-in for the reference's ``latent_backward_guidance``.
+
+Reference interfaces mirrored here
+  models/pipelines.py:21-150                latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes,
+                                            object_positions, t, latents, loss, loss_scale, loss_threshold, max_iter,
+                                            max_index_step, cross_attention_kwargs, guidance_attn_keys, verbose,
+                                            return_saved_attn, clear_cache, **kwargs) -> (latents, loss[, saved_attn])
+  utils/guidance.py:529-574,160-526         compute_ca_lossv3 / add_ca_loss_per_attn_map_to_loss (max-based top-k
+                                            energy + centre-of-mass terms)
+  models/controllable_pipeline_text_to_video_synth.py:572,827-831   the ``custom_latent_backward_guidance`` hook
+
+What runs on the GPU per guidance iteration: a recorded forward of the cond branch that stops right after the query
+projection of the last guidance key, three fused loss kernels per key (csrc/guidance_loss.hip) that produce the loss
+and d(loss)/dQ without ever materialising an attention map, and the hand-scheduled input-gradient tape back to the
+latents.  No torch autograd graph exists at any point.
+"""
+import math
+import warnings
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from .engine import HipUNet3D, Tape, Geom
+
+DEFAULT_GUIDANCE_ATTN_KEYS = [("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0)]  # models/pipelines.py:13-18
+
+_UNSUPPORTED = dict(use_ratio_based_loss=False, use_ce_based_loss=False, exclude_bg_heads=False, smooth_attn=False,
+                    attn_renorm=False, attn_sync_weight=0.0, boxdiff_loss_scale=0.0, upsample_scale=1)
+
+
+def scale_proportion(box, H, W):
+    """utils/utils.py:82-103 (non-legacy branch; Python banker's rounding is part of the contract)."""
+    x_min, y_min = round(box[0] * W), round(box[1] * H)
+    bw, bh = round((box[2] - box[0]) * W), round((box[3] - box[1]) * H)
+    x_max, y_max = x_min + bw, y_min + bh
+    return max(x_min, 0), max(y_min, 0), min(x_max, W), min(y_max, H)
+
+
+def _topk_count(n, p):
+    # (mask.sum() * top_p).long().clamp_(min=1) with a float32 mask sum (utils/guidance.py:328-337)
+    return max(1, int(np.float32(n) * np.float32(p)))
+
+
+class GuidanceLayout:
+    """Device-side description of the boxes / object tokens for one attention resolution (H, W)."""
+
+    def __init__(self, bboxes, object_positions, frames, H, W, fg_top_p, bg_top_p, device):
+        nobj = len(bboxes)
+        arr = np.zeros((nobj, frames, 6), dtype=np.int32)
+        for o, obj_boxes in enumerate(bboxes):
+            assert len(obj_boxes) == frames, f"Number of frames {frames} mismatches with number of frames in box condition {len(obj_boxes)}"
+            for f, box in enumerate(obj_boxes):
+                x0, y0, x1, y1 = scale_proportion(box, H, W)
+                n = max(0, x1 - x0) * max(0, y1 - y0)
+                arr[o, f] = (x0, y0, x1, y1, _topk_count(n, fg_top_p), _topk_count(H * W - n, bg_top_p))
+        tok_ids, tok_obj, tok_w = [], [], []
+        for o, positions in enumerate(object_positions):
+            for pos in positions:
+                tok_ids.append(int(pos))
+                tok_obj.append(o)
+                tok_w.append(1.0 / len(positions))
+        self.nobj, self.ntok, self.H, self.W = nobj, len(tok_ids), H, W
+        self.boxes = torch.from_numpy(arr).to(device)
+        self.tok_ids = torch.tensor(tok_ids, dtype=torch.int32, device=device)
+        self.tok_obj = torch.tensor(tok_obj, dtype=torch.int32, device=device)
+        self.tok_weight = torch.tensor(tok_w, dtype=torch.float32, device=device)
+
+
+def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext, grad_scale, fg_weight, bg_weight,
+                          com_loss_scale, loss_partial, want_dq=True):
+    """One guidance key: q [frames*P, heads*64] bf16, k [ntext, heads*64] bf16 (strided ok).
+
+    Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ."""
+    dev = q.device
+    P = layout.H * layout.W
+    assert q.shape[0] == frames * P, (q.shape, frames, P)
+    st = torch.cuda.current_stream().cuda_stream
+    probs = torch.empty((frames, heads, layout.ntok, P), dtype=torch.float32, device=dev)
+    lse = torch.empty((frames, heads, P), dtype=torch.float32, device=dev)
+    a = hip.CaProbsParams()
+    a.q, a.ldq, a.k, a.ldk = q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0)
+    a.frames, a.heads, a.P, a.ntext, a.scale = frames, heads, P, ntext, 0.125
+    a.tok_ids, a.ntok, a.probs, a.lse = layout.tok_ids.data_ptr(), layout.ntok, probs.data_ptr(), lse.data_ptr()
+    hip.check(hip.lib().lvdhip_ca_probs(C.byref(a), st), "ca_probs")
+
+    dprobs = torch.empty_like(probs)
+    com_ws = torch.empty((frames, heads, layout.ntok, 4), dtype=torch.float32, device=dev)
+    b = hip.CaSelectParams()
+    b.probs, b.dprobs = probs.data_ptr(), dprobs.data_ptr()
+    b.frames, b.heads, b.P, b.ntok, b.H, b.W = frames, heads, P, layout.ntok, layout.H, layout.W
+    b.tok_obj, b.boxes, b.tok_weight, b.nobj = layout.tok_obj.data_ptr(), layout.boxes.data_ptr(), layout.tok_weight.data_ptr(), layout.nobj
+    b.fg_weight, b.bg_weight, b.com_loss_scale, b.grad_scale = fg_weight, bg_weight, com_loss_scale, grad_scale
+    b.loss_partial, b.com_ws = loss_partial.data_ptr(), com_ws.data_ptr()
+    hip.check(hip.lib().lvdhip_ca_select(C.byref(b), st), "ca_select")
+    if not want_dq:
+        return None
+    dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev)
+    c = hip.CaDqParams()
+    c.q, c.ldq, c.k, c.ldk = a.q, a.ldq, a.k, a.ldk
+    c.frames, c.heads, c.P, c.ntext, c.scale = frames, heads, P, ntext, 0.125
+    c.tok_ids, c.ntok = a.tok_ids, a.ntok
+    c.probs, c.dprobs, c.lse = probs.data_ptr(), dprobs.data_ptr(), lse.data_ptr()
+    c.dq, c.lddq = dq.data_ptr(), dq.stride(0)
+    hip.check(hip.lib().lvdhip_ca_dq(C.byref(c), st), "ca_dq")
+    return dq
+
+
+def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_positions, guidance_attn_keys, *, loss_scale,
+                           fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0, com_loss_scale=0.0, latent_scale=1.0):
+    """One recorded forward + fused loss + hand-scheduled backward.
+
+    Returns (loss [1] fp32 device tensor, already multiplied by loss_scale; grad (1,4,F,h,w) fp32)."""
+    assert latents.shape[0] == 1, "guidance runs on the cond branch only (batch 1), models/pipelines.py:78"
+    keys = [tuple(k) for k in guidance_attn_keys]
+    tape = Tape()
+    collect = {"keys": set(keys), "q": {}, "stop_after": _last_key_in_order(engine, keys)}
+    engine.forward(latents, t, text=text, tape=tape, collect=collect)
+    missing = [k for k in keys if k not in collect["q"]]
+    if missing:
+        raise KeyError(f"guidance keys not produced by this UNet: {missing}")
+    nobj = len(bboxes)
+    frames = latents.shape[2]
+    grad_scale = loss_scale / (nobj * len(keys))
+    layouts = {}
+    sizes = []
+    for key in keys:
+        q, k, heads, g = collect["q"][key]
+        sizes.append(frames * heads * sum(len(p) for p in object_positions))
+    partial = torch.empty((sum(sizes),), dtype=torch.float32, device=latents.device)
+    off = 0
+    for key, n in zip(keys, sizes):
+        q, k, heads, g = collect["q"][key]
+        lay = layouts.get((g.H, g.W))
+        if lay is None:
+            lay = layouts[(g.H, g.W)] = GuidanceLayout(bboxes, object_positions, frames, g.H, g.W, fg_top_p, bg_top_p, latents.device)
+        dq = ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=text.ntext, grad_scale=grad_scale, fg_weight=fg_weight,
+                                   bg_weight=bg_weight, com_loss_scale=com_loss_scale, loss_partial=partial[off:off + n])
+        tape.accumulate(q, dq)
+        off += n
+    loss = ops.reduce_sum(partial, grad_scale)
+    tape.backward()
+    g0 = Geom(1, frames, latents.shape[3], latents.shape[4])
+    grad = engine.input_gradient(tape, g0, scale=latent_scale)
+    return loss, grad
+
+
+def _key_order(engine):
+    cfg = engine.cfg
+    order = []
+    for i, bt in enumerate(cfg.down_block_types):
+        if bt == "CrossAttnDownBlock3D":
+            order += [("down", i, j, 0) for j in range(cfg.layers_per_block)]
+    order.append(("mid", 0, 0, 0))
+    for i, bt in enumerate(cfg.up_block_types):
+        if bt == "CrossAttnUpBlock3D":
+            order += [("up", i, j, 0) for j in range(cfg.layers_per_block + 1)]
+    return order
+
+
+def _last_key_in_order(engine, keys):
+    order = _key_order(engine)
+    unknown = [k for k in keys if k not in order]
+    if unknown:
+        raise KeyError(f"unknown guidance attention keys {unknown}")
+    return max(keys, key=order.index)
+
+
+def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes, object_positions, t, latents, loss,
+                                 loss_scale=30, loss_threshold=0.2, max_iter=5, max_index_step=10, cross_attention_kwargs=None,
+                                 guidance_attn_keys=None, verbose=False, return_saved_attn=False, clear_cache=False, **kwargs):
+    """Same call contract as models/pipelines.py:21-150; plugs into ``custom_latent_backward_guidance``.
+
+    ``unet`` is anything exposing ``.engine`` (HipUNet3D) or the engine itself; ``cond_embeddings`` (1,77,D) or a
+    TextCache.  ``loss`` is the carried loss (tensor or float).  Unsupported loss variants raise instead of
+    silently computing something else."""
+    engine = getattr(unet, "engine", unet)
+    for k, default in _UNSUPPORTED.items():
+        if k in kwargs and kwargs[k] != default:
+            raise NotImplementedError(f"guidance option {k}={kwargs[k]!r} is outside the hot path built here")
+    if return_saved_attn:
+        raise NotImplementedError("attention maps are never materialised on the HIP path (return_saved_attn)")
+    if guidance_attn_keys is None:
+        guidance_attn_keys = DEFAULT_GUIDANCE_ATTN_KEYS
+    loss_kw = {k: kwargs[k] for k in ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "com_loss_scale") if k in kwargs}
+    text = cond_embeddings if hasattr(cond_embeddings, "kv") else engine.encode_text(cond_embeddings)
+    iteration = 0
+    loss_val = float(loss)
+    if index < max_index_step:
+        if isinstance(max_iter, list):
+            max_iter = max_iter[index]
+        if verbose:
+            print(f"time index {index}, loss: {loss_val / loss_scale:.3f} (de-scaled with scale {loss_scale:.1f}), loss threshold: {loss_threshold:.3f}")
+        if len(bboxes) == 0:
+            # the reference crashes in autograd here and generate.py skips the prompt; no boxes = no guidance
+            return latents, torch.zeros((), device=latents.device)
+        while loss_val / loss_scale > loss_threshold and iteration < max_iter and index < max_index_step:
+            lat_in = scheduler.scale_model_input(latents, t) if hasattr(scheduler, "scale_model_input") else latents
+            loss_t, grad = guidance_loss_and_grad(engine, lat_in, t, text, bboxes, object_positions, guidance_attn_keys,
+                                                  loss_scale=loss_scale, **loss_kw)
+            if hasattr(scheduler, "alphas_cumprod"):
+                scale = float((1 - scheduler.alphas_cumprod[int(t)]) ** 0.5)  # classifier-guidance scaling, pipelines.py:124-132
+            else:
+                warnings.warn("No scaling in guidance is performed")
+                scale = 1.0
+            latents = ops.axpy_(latents.to(torch.float32).contiguous().clone(), grad, scale)
+            loss_val = float(loss_t.item())  # one host sync per iteration, as the reference's loss.item()
+            if math.isnan(loss_val):
+                print("**Loss is NaN**")
+            loss = loss_t
+            iteration += 1
+            if verbose:
+                print(f"time index {index}, loss: {loss_val / loss_scale:.3f}, loss threshold: {loss_threshold:.3f}, iteration: {iteration}")
+    return latents, loss

@@ -117,7 +117,7 @@ class CaSelectParams(C.Structure):
         ("probs", C.c_void_p), ("dprobs", C.c_void_p),
         ("frames", i32), ("heads", i32), ("P", i32), ("ntok", i32), ("H", i32), ("W", i32),
         ("tok_obj", C.c_void_p), ("boxes", C.c_void_p), ("tok_weight", C.c_void_p), ("nobj", i32),
-        ("fg_top_p", f32), ("bg_top_p", f32), ("fg_weight", f32), ("bg_weight", f32), ("com_loss_scale", f32),
+        ("fg_weight", f32), ("bg_weight", f32), ("com_loss_scale", f32),
         ("grad_scale", f32), ("loss_partial", C.c_void_p), ("com_ws", C.c_void_p),
     ]
 

@@ -197,25 +197,28 @@ def _seed_for(name, seed):
     return int.from_bytes(h[:8], "little") % (2**63 - 1)
 
 
-def synthetic_state_dict(cfg: UNetConfig, seed: int = 0, gain: float = 1.0):
-    """Per-parameter seeded fp32 tensors, rounded to bf16-representable values."""
+def synthetic_state_dict(cfg: UNetConfig, seed: int = 0, gain: float = 1.0, device="cpu"):
+    """Per-parameter seeded fp32 tensors, rounded to bf16-representable values.
+
+    device="cpu" (default) is bit-reproducible everywhere and is what the parity fixtures use;
+    device="cuda" draws on the GPU (fast path for the 1.4 B-parameter benchmark model)."""
     sd = OrderedDict()
     for name, shape in unet_param_shapes(cfg).items():
-        g = torch.Generator().manual_seed(_seed_for(name, seed))
+        g = torch.Generator(device=device).manual_seed(_seed_for(name, seed))
         leaf = name.rsplit(".", 1)[-1]
         if shape == ():
-            t = torch.tensor(0.6 if name.endswith("alpha_attn") else -0.4)
+            t = torch.tensor(0.6 if name.endswith("alpha_attn") else -0.4, device=device)
         elif leaf == "weight" and len(shape) == 1:  # norm gamma
-            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
         elif leaf == "bias":
-            t = 0.05 * torch.randn(shape, generator=g)
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
         elif len(shape) == 1:  # null features
-            t = 0.5 * torch.randn(shape, generator=g)
+            t = 0.5 * torch.randn(shape, generator=g, device=device)
         else:
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            t = gain * torch.randn(shape, generator=g) / math.sqrt(fan_in)
+            t = gain * torch.randn(shape, generator=g, device=device) / math.sqrt(fan_in)
         sd[name] = t.to(torch.bfloat16).to(torch.float32)
     return sd
 

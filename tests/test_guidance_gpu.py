@@ -1,0 +1,128 @@
+"""GPU parity of the guidance path: attention backward, fused loss fwd+bwd, and the whole
+latent_backward_guidance step against the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import lvd_amd  # noqa: E402
+from lvd_amd import guidance, ops  # noqa: E402
+from lvd_amd.engine import HipUNet3D  # noqa: E402
+from lvd_amd.weights import TINY, UNetConfig, synthetic_state_dict  # noqa: E402
+from oracle import guidance_ref, scheduler_ref  # noqa: E402
+
+DEV = "cuda"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DEV)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("mode", ["spatial", "temporal", "cross"])
+def test_attention_backward(mode):
+    H = 2
+    C = H * 64
+    if mode == "spatial":
+        S, sq, skv = 3, 70, 70
+        rows = S * sq
+        qm = km = ops.RowMap(1, sq, 0, 1)
+        perm = lambda t, L: t.reshape(S, L, H, 64).permute(0, 2, 1, 3)
+        unperm = lambda t: t.permute(0, 2, 1, 3).reshape(-1, C)
+    elif mode == "temporal":
+        Bt, Fr, hw = 2, 24, 10
+        S, sq, skv = Bt * hw, Fr, Fr
+        rows = Bt * Fr * hw
+        qm = km = ops.RowMap(hw, Fr * hw, 1, hw)
+        perm = lambda t, L: t.reshape(Bt, Fr, hw, H, 64).permute(0, 2, 3, 1, 4).reshape(S, H, Fr, 64)
+        unperm = lambda t: t.reshape(Bt, hw, H, Fr, 64).permute(0, 3, 1, 2, 4).reshape(-1, C)
+    else:
+        Bt, Fr, sq, skv = 1, 3, 50, 77
+        S = Bt * Fr
+        rows = S * sq
+        qm, km = ops.RowMap(1, sq, 0, 1), ops.RowMap(Fr, skv, 0, 1)
+    q = rnd(rows, C, seed=1).bfloat16()
+    if mode == "cross":
+        k, v = rnd(skv, C, seed=2).bfloat16(), rnd(skv, C, seed=3).bfloat16()
+    else:
+        k, v = rnd(rows, C, seed=2).bfloat16(), rnd(rows, C, seed=3).bfloat16()
+    do = rnd(rows, C, seed=4).bfloat16()
+    o = torch.empty_like(q)
+    lse = torch.empty(S, H, sq, device=DEV)
+    kw = dict(samples=S, heads=H, sq=sq, skv=skv, qmap=qm, kvmap=km, scale=0.125)
+    ops.attention_fwd(q, k, v, o, lse=lse, **kw)
+    dq = torch.zeros_like(q)
+    dk = torch.zeros_like(k) if mode != "cross" else None
+    dv = torch.zeros_like(v) if mode != "cross" else None
+    ops.attention_bwd(q, k, v, o, lse, do, dq, dk, dv, **kw)
+    qa, ka, va = (t.float().requires_grad_(True) for t in (q, k, v))
+    if mode == "cross":
+        qs = qa.reshape(S, sq, H, 64).permute(0, 2, 1, 3)
+        ks = ka.reshape(1, skv, H, 64).permute(0, 2, 1, 3).expand(S, -1, -1, -1)
+        vs = va.reshape(1, skv, H, 64).permute(0, 2, 1, 3).expand(S, -1, -1, -1)
+        out = ((qs @ ks.transpose(-1, -2) * 0.125).softmax(-1) @ vs).permute(0, 2, 1, 3).reshape(rows, C)
+    else:
+        qs, ks, vs = perm(qa, sq), perm(ka, skv), perm(va, skv)
+        out = unperm((qs @ ks.transpose(-1, -2) * 0.125).softmax(-1) @ vs)
+    gq, gk, gv = torch.autograd.grad(out, [qa, ka, va], do.float())
+    assert rel(dq, gq) < 1.5e-2, ("dq", rel(dq, gq))
+    if mode != "cross":
+        assert rel(dk, gk) < 1.5e-2, ("dk", rel(dk, gk))
+        assert rel(dv, gv) < 1.5e-2, ("dv", rel(dv, gv))
+
+
+@pytest.mark.parametrize("com", [0.0, 0.03])
+def test_fused_loss_kernels_vs_oracle(com):
+    frames, heads, Hh, Ww, nt = 4, 3, 8, 12, 77
+    P, C = Hh * Ww, heads * 64
+    q = rnd(frames * P, C, seed=1, scale=1.5).bfloat16()
+    kv = rnd(nt, 2 * C, seed=2).bfloat16()
+    k = kv[:, :C]
+    bboxes = [[[0.1, 0.2, 0.55, 0.8], [0.15, 0.2, 0.6, 0.8], [0.2, 0.2, 0.65, 0.8], [0.25, 0.2, 0.7, 0.8]],
+              [[0.5, 0.5, 0.9, 0.95], [0.0, 0.0, 0.0, 0.0], [0.4, 0.45, 0.8, 0.9], [0.35, 0.4, 0.75, 0.85]]]
+    pos = [[2, 3], [6]]
+    hp = dict(fg_top_p=0.3, bg_top_p=0.4, fg_weight=1.0, bg_weight=2.0, com_loss_scale=com)
+    loss_scale, nkeys = 5.0, 1
+    qa = q.float().requires_grad_(True)
+    probs = (qa.reshape(frames, P, heads, 64).permute(0, 2, 1, 3) @ k.float().reshape(nt, heads, 64).permute(1, 2, 0)[None] * 0.125).softmax(-1)
+    ref = guidance_ref.compute_ca_loss({"k": probs}, bboxes, pos, ["k"], (Hh, Ww), **hp) * loss_scale
+    (gq,) = torch.autograd.grad(ref, qa)
+    lay = guidance.GuidanceLayout(bboxes, pos, frames, Hh, Ww, hp["fg_top_p"], hp["bg_top_p"], DEV)
+    partial = torch.zeros(frames * heads * 3, device=DEV)
+    gs = loss_scale / (len(bboxes) * nkeys)
+    dq = guidance.ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=nt, grad_scale=gs, fg_weight=1.0, bg_weight=2.0,
+                                        com_loss_scale=com, loss_partial=partial)
+    loss = ops.reduce_sum(partial, gs).item()
+    assert abs(loss - ref.item()) < 2e-4 * abs(ref.item()), (loss, ref.item())
+    assert rel(dq, gq) < 1.5e-2, rel(dq, gq)   # dq is stored in bf16
+
+
+def test_guidance_step_vs_reference_golden():
+    """Latents after latent_backward_guidance (1 and 2 iterations) vs the reference run (fp32 CPU).
+    Tolerance: loss 2e-2 relative, latent update rel-L2 0.08 (bf16 trunk forward+backward vs fp32)."""
+    g = np.load(os.path.join(G, "guidance_step.npz"))
+    cfg = UNetConfig(**TINY)
+    net = HipUNet3D(cfg, synthetic_state_dict(cfg, seed=0))
+    keys = [tuple(int(x) if x.isdigit() else x for x in k.split("_")) for k in g["keys"]]
+    sched = scheduler_ref.DPMSolverPP2M()
+    lat0 = torch.from_numpy(g["latents_in"]).to(DEV)
+    cond = torch.from_numpy(g["cond"]).to(DEV)
+    hp = dict(loss_scale=5.0, loss_threshold=0.01, max_index_step=10, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0,
+              com_loss_scale=0.03, guidance_attn_keys=keys)
+    for iters, suffix in ((1, "_1"), (2, "")):
+        lat, loss = guidance.hip_latent_backward_guidance(sched, net, cond, 0, g["bboxes"].tolist(), [[2]], int(g["t"]), lat0.clone(),
+                                                          torch.tensor(10000.0), max_iter=iters, **hp)
+        ref_loss = float(g["loss" + suffix])
+        d = lat - lat0
+        d_ref = torch.from_numpy(g["latents_out" + suffix]).to(DEV) - lat0
+        print(f"iters={iters}: loss {float(loss):.4f} vs ref {ref_loss:.4f}; update rel-L2 {rel(d, d_ref):.4f}; |d| {d.abs().mean().item():.3e} vs {d_ref.abs().mean().item():.3e}")
+        assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
+        assert rel(d, d_ref) < 0.08
