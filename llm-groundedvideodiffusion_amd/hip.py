@@ -175,6 +175,9 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no fallback path."
             )
+        # torch bundles its own libamdhip64; it must be the HIP runtime already resident when liblvdhip.so is
+        # loaded, otherwise two runtimes coexist and the streams torch hands us belong to the other one.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, argtypes in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
