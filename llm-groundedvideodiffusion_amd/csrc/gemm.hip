@@ -13,11 +13,12 @@
 // ds_read_b128 fragment reads are conflict-free, XCD-aware block->tile map (consecutive tiles of an
 // XCD share the A row-panel in that XCD's L2).  Epilogue goes through LDS so that bias / temb row
 // bias / GEGLU / gate / residual are applied on 8-16 byte row-contiguous vectors.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 
 struct ARow {
   long off1, off2;  // PLAIN: row offsets; CONV: image base row (off1) ; TCONV: row index m (off1)
@@ -64,9 +65,15 @@ LVD_DEV uint4 load_a(const lvd_gemm_params& p, const ARow& r, int k0) {
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
-  __shared__ uint4 lds[2 * (BM + BN) * 8];  // 64 KiB: 2 buffers x (A 128 rows + B 128 rows) x 8 x 16 B
+// BK = K-tile depth (64: 64 KiB LDS, 2 workgroups/CU; 32: 32 KiB LDS, up to 4 workgroups/CU), MINW = waves/SIMD the
+// register allocator must leave room for.
+template <int MODE, int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p) {
+  constexpr int CH = BK / 8;            // 16-byte chunks per tile row
+  constexpr int NLD = (BM * CH) / 256;  // 16-byte loads per thread per operand per K tile
+  constexpr int RSTEP = 256 / CH;       // row distance between a thread's loads
+  constexpr int TILE = (BM + BN) * CH;  // uint4 per buffer
+  __shared__ uint4 lds[2 * TILE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,15 +93,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tm = id / tiles_n, tn = id - tm * tiles_n;
 
-  const int vc = tid & 7;   // 16-byte chunk (8 bf16) within the 64-wide K tile
-  const int r0 = tid >> 3;  // 0..31
+  const int vc = tid % CH;  // 16-byte chunk (8 bf16) within the K tile
+  const int r0 = tid / CH;
 
-  ARow ar[4];
-  long woff[4];
-  bool wvalid[4];
+  ARow ar[NLD];
+  long woff[NLD];
+  bool wvalid[NLD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = tm * BM + r0 + 32 * i;
+  for (int i = 0; i < NLD; ++i) {
+    int m = tm * BM + r0 + RSTEP * i;
     ar[i].valid = m < p.M;
     ar[i].off1 = 0; ar[i].off2 = 0; ar[i].oy = 0; ar[i].ox = 0;
     if (MODE == LVD_A_PLAIN) {
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
       ar[i].off1 = m;
       ar[i].oy = (m / p.hw) % p.frames;
     }
-    int n = tn * BN + r0 + 32 * i;
+    int n = tn * BN + r0 + RSTEP * i;
     wvalid[i] = n < p.N;
     woff[i] = (long)n * p.K;
   }
@@ -127,25 +134,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (p.K + BK - 1) / BK;
-  uint4 ra[4], rb[4];
+  uint4 ra[NLD], rb[NLD];
+
+  // XOR swizzle of the 16-byte chunk index so that the 16-lane groups of ds_read_b128 hit 16 distinct slots of
+  // the 256-byte bank row: BK=64 (128-byte rows): c ^ ((row>>1)&7);  BK=32 (64-byte rows): c ^ ((row>>2)&3)
+  auto swz = [](int row, int c) { return BK == 64 ? (c ^ ((row >> 1) & 7)) : (c ^ ((row >> 2) & 3)); };
 
   auto load_tile = [&](int kt) {
     int k0 = kt * BK + vc * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = load_a<MODE>(p, ar[i], k0);
+    for (int i = 0; i < NLD; ++i) ra[i] = load_a<MODE>(p, ar[i], k0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NLD; ++i)
       rb[i] = (wvalid[i] && k0 < p.K) ? ldg16(p.w + woff[i] + k0) : make_uint4(0, 0, 0, 0);
   };
   auto store_tile = [&](int buf) {
-    uint4* A = lds + buf * 2048;
-    uint4* B = A + 1024;
+    uint4* A = lds + buf * TILE;
+    uint4* B = A + BM * CH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int row = r0 + 32 * i;
-      int sw = vc ^ ((row >> 1) & 7);
-      A[row * 8 + sw] = ra[i];
-      B[row * 8 + sw] = rb[i];
+    for (int i = 0; i < NLD; ++i) {
+      int row = r0 + RSTEP * i;
+      int sw = swz(row, vc);
+      A[row * CH + sw] = ra[i];
+      B[row * CH + sw] = rb[i];
     }
   };
 
@@ -156,20 +167,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const uint4* A = lds + cur * 2048;
-    const uint4* B = A + 1024;
+    const uint4* A = lds + cur * TILE;
+    const uint4* B = A + BM * CH;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         int row = wm * 64 + i * 32 + l31;
-        af[i] = as_bf16x8(A[row * 8 + ((ks * 2 + hi) ^ ((row >> 1) & 7))]);
+        af[i] = as_bf16x8(A[row * CH + swz(row, ks * 2 + hi)]);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int row = wn * 64 + j * 32 + l31;
-        bfr[j] = as_bf16x8(B[row * 8 + ((ks * 2 + hi) ^ ((row >> 1) & 7))]);
+        bfr[j] = as_bf16x8(B[row * CH + swz(row, ks * 2 + hi)]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -181,82 +192,103 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lvd_gemm_params p) {
     __syncthreads();
   }
 
-  // ---- epilogue: stage the wave's 64x64 fp32 tile in LDS, then row-contiguous vector math ----
-  float* S = reinterpret_cast<float*>(lds) + wave * 4096;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int rowl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        S[rowl * 64 + j * 32 + l31] = acc[i][j][e];
-      }
-  __syncthreads();
-
+  // ---- epilogue: stage the wave's fp32 tile in LDS (RP rows per pass), then row-contiguous vector math ----
+  constexpr int RP = BK;             // rows per pass: the wave's LDS share is TILE*2*16/4 bytes = RP rows x 64 fp32
+  constexpr int NP = 64 / RP;        // passes (BK=64: 1, BK=32: 2)
+  float* S = reinterpret_cast<float*>(lds) + wave * (RP * 64);
   const int mbase = tm * BM + wm * 64;
   const int nbase = tn * BN + wn * 64;
-
-  if (p.act == LVD_ACT_GEGLU) {
-    const int ldc = p.ldc;
-    lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      int idx = it * 64 + lane;
-      int row = idx >> 3, cq = idx & 7;
-      int m = mbase + row;
-      int n = nbase + cq * 4;  // hidden column in the interleaved W'; gate = n + 32
-      if (m >= p.M || n + 32 >= p.N) continue;
-      f32x4 h = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
-      f32x4 g = *reinterpret_cast<const f32x4*>(&S[row * 64 + 32 + cq * 4]);
-      if (p.bias) {
-        f32x4 bh = *reinterpret_cast<const f32x4*>(p.bias + n);
-        f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-        h += bh; g += bg;
+  for (int ps = 0; ps < NP; ++ps) {
+    if (ps > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (NP == 2 && i != ps) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int rowl = (NP == 2 ? 0 : i * 32) + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          S[rowl * 64 + j * 32 + l31] = acc[i][j][e];
+        }
+    }
+    __syncthreads();
+    const int mrow0 = mbase + ps * RP;
+
+    if (p.act == LVD_ACT_GEGLU) {
+      const int ldc = p.ldc;
+      lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
+#pragma unroll
+      for (int it = 0; it < RP / 8; ++it) {
+        int idx = it * 64 + lane;
+        int row = idx >> 3, cq = idx & 7;
+        int m = mrow0 + row;
+        int n = nbase + cq * 4;  // hidden column in the interleaved W'; gate = n + 32
+        if (m >= p.M || n + 32 >= p.N) continue;
+        f32x4 h = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
+        f32x4 g = *reinterpret_cast<const f32x4*>(&S[row * 64 + 32 + cq * 4]);
+        if (p.bias) {
+          h += *reinterpret_cast<const f32x4*>(p.bias + n);
+          g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+        }
+        int oc = (nbase >> 1) + cq * 4;
+        uint2 o;
+        o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
+        o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+        stg8(out + (long)m * ldc + oc, o);
       }
-      int oc = (nbase >> 1) + cq * 4;
-      uint2 o;
-      o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-      o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
-      stg8(out + (long)m * ldc + oc, o);
+      continue;
     }
-    return;
-  }
 
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    int idx = it * 64 + lane;
-    int row = idx >> 4, cq = idx & 15;
-    int m = mbase + row;
-    int n = nbase + cq * 4;
-    if (m >= p.M || n >= p.N) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
-    v *= p.alpha;
-    if (p.res) {
-      uint2 r = ldg8(p.res + (long)m * p.ldres + n);
-      v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
-    }
-    if (p.out_fp32) {
-      float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
-      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
-      *reinterpret_cast<f32x4*>(o) = v;
-    } else {
-      lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
-      if (p.accumulate) {
-        uint2 r = ldg8(o);
+    for (int it = 0; it < RP / 4; ++it) {
+      int idx = it * 64 + lane;
+      int row = idx >> 4, cq = idx & 15;
+      int m = mrow0 + row;
+      int n = nbase + cq * 4;
+      if (m >= p.M || n >= p.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
+      v *= p.alpha;
+      if (p.res) {
+        uint2 r = ldg8(p.res + (long)m * p.ldres + n);
         v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
       }
-      uint2 w;
-      w.x = pack2bf(v[0], v[1]);
-      w.y = pack2bf(v[2], v[3]);
-      stg8(o, w);
+      if (p.out_fp32) {
+        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+      } else {
+        lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+        if (p.accumulate) {
+          uint2 r = ldg8(o);
+          v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+        }
+        uint2 w;
+        w.x = pack2bf(v[0], v[1]);
+        w.y = pack2bf(v[2], v[3]);
+        stg8(o, w);
+      }
     }
   }
 }
 
+template <int BK, int MINW>
+int launch_gemm(const lvd_gemm_params* p, dim3 grid, hipStream_t s) {
+  switch (p->mode) {
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<LVD_A_PLAIN, BK, MINW>), grid, dim3(256), 0, s, *p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<LVD_A_CONV3X3, BK, MINW>), grid, dim3(256), 0, s, *p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_kernel<LVD_A_TCONV3, BK, MINW>), grid, dim3(256), 0, s, *p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_kernel<LVD_A_CONV3X3_T2, BK, MINW>), grid, dim3(256), 0, s, *p); break;
+    default: return 1;
+  }
+  return 0;
+}
+
 }  // namespace
+
+int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_ring.hip
 
 extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   LVD_CHECK(p && p->a1 && p->w && p->out, "gemm: null pointer");
@@ -272,15 +304,30 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
     LVD_CHECK(p->K == 9 * p->cin && p->hout > 0 && p->wout > 0 && p->hin > 0 && p->win > 0 && p->M % (p->hout * p->wout) == 0,
               "gemm: bad conv dims");
   int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
-  dim3 grid(tiles), block(256);
+  dim3 grid(tiles);
   hipStream_t s = (hipStream_t)stream;
-  switch (p->mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL(gemm_kernel<LVD_A_PLAIN>, grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3: hipLaunchKernelGGL(gemm_kernel<LVD_A_CONV3X3>, grid, block, 0, s, *p); break;
-    case LVD_A_TCONV3: hipLaunchKernelGGL(gemm_kernel<LVD_A_TCONV3>, grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL(gemm_kernel<LVD_A_CONV3X3_T2>, grid, block, 0, s, *p); break;
-    default: LVD_CHECK(false, "gemm: unknown mode %d", p->mode);
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("LVD_GEMM_VARIANT");  // developer knob for A/B runs (tools/gemm_bench.py)
+    variant = e ? atoi(e) : 0;
   }
+  int v = variant;
+  if (v == 0) {
+    // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_variants.txt):
+    //   under-filled grids            -> 128x128x64 register-staged (fewest, longest tiles)
+    //   conv / tconv / long-K linear  -> LDS-DMA ring, 3 stages, 3 workgroups per CU
+    //   short-K linear                -> 128x128x32 register-staged, 4 workgroups per CU
+    if (tiles < 400) v = 10;
+    else if (p->mode != LVD_A_PLAIN || p->K >= 1024) v = 5;
+    else v = 1;
+  }
+  int rc;
+  if (v >= 5 && v <= 8) rc = lvd_gemm_ring_dispatch(p, stream, v - 5);
+  else if (v == 9) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
+  else if (v == 1) rc = launch_gemm<32, 3>(p, grid, s);
+  else if (v == 2) rc = launch_gemm<32, 4>(p, grid, s);
+  else rc = launch_gemm<64, 2>(p, grid, s);
+  LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,345 @@
+// gemm_ring.hip — LDS-DMA ring-buffered MFMA GEMM (second generation of gemm.hip, same lvd_gemm_params contract).
+//
+// PMC counters on the first kernel (register-staged, one K tile of prefetch, vmcnt(0)+barrier per tile) showed
+// MFMA busy 17-34 %, waves parked in s_waitcnt/s_barrier ~40 % and zero LDS bank conflicts: the loads of tile k+1
+// are issued one tile (~0.3 us of MFMA work) before they are needed, less than the loaded HBM/L2 latency.
+// This kernel keeps STAGES-1 K tiles in flight:
+//   * both operands go global -> LDS by global_load_lds (16 B per lane, no staging VGPRs, no ds_write issue slots);
+//     conv padding and M/N/K tails are redirected to a 16-byte zero page instead of being predicated;
+//   * counted s_waitcnt vmcnt(N) + raw s_barrier: only the tile about to be consumed is waited for, the
+//     STAGES-2 younger tiles stay in flight across the barrier (hipcc's __syncthreads would drain them);
+//   * one barrier per K tile; the slot that was consumed in iteration k-1 is refilled right after the barrier.
+// Geometry is a template: WMxWN waves, each owning an (FM*32)x(FN*32) accumulator tile.
+//   128x128 (2x2 waves, 2x2 frags)  — small/odd shapes, most workgroups per CU
+//   256x160 (4x1 waves, 2x5 frags)  — the model's channel counts are multiples of 160 (320·k): no wasted columns,
+//                                     0.7 LDS fragment reads per MFMA instead of 1.0
+//   256x128 (4x1 waves, 2x4 frags)  — GEGLU projections (hidden/gate pairs need an even fragment count)
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+constexpr int RBK = 32, RCH = 4;  // K depth per stage, 16-byte chunks per row
+
+__device__ uint4 g_zero_page[4];
+
+struct RowInfo {
+  long off1, off2;
+  int oy, ox;
+  bool valid;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Source address of one 16-byte chunk of the A operand; written with selects (no divergent branches around the DMA).
+template <int MODE>
+LVD_DEV const lvd_bf16* a_src(const lvd_gemm_params& p, const RowInfo& r, int k0) {
+  const lvd_bf16* z = reinterpret_cast<const lvd_bf16*>(g_zero_page);
+  bool ok = r.valid && k0 < p.K;
+  const lvd_bf16* base;
+  long off;
+  if (MODE == LVD_A_PLAIN) {
+    bool s2 = k0 >= p.c1;
+    base = s2 ? p.a2 : p.a1;
+    off = s2 ? r.off2 + (k0 - p.c1) : r.off1 + k0;
+  } else if (MODE == LVD_A_CONV3X3) {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ky = tap / 3, kx = tap - 3 * ky;
+    int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
+    ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
+    int ws = p.win >> p.upsample;
+    iy >>= p.upsample; ix >>= p.upsample;
+    long row = r.off1 + (long)iy * ws + ix;
+    bool s2 = c >= p.c1;
+    base = s2 ? p.a2 : p.a1;
+    off = s2 ? row * p.lda2 + (c - p.c1) : row * p.lda1 + c;
+  } else if (MODE == LVD_A_CONV3X3_T2) {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ky = tap / 3, kx = tap - 3 * ky;
+    int ty = r.oy + 1 - ky, tx = r.ox + 1 - kx;
+    ok = ok && ty >= 0 && tx >= 0 && !((ty | tx) & 1);
+    ty >>= 1; tx >>= 1;
+    ok = ok && ty < p.hin && tx < p.win;
+    base = p.a1;
+    off = (r.off1 + (long)ty * p.win + tx) * p.lda1 + c;
+  } else {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ff = r.oy + tap - 1;
+    ok = ok && ff >= 0 && ff < p.frames;
+    long row = r.off1 + (long)(tap - 1) * p.hw;
+    bool s2 = c >= p.c1;
+    base = s2 ? p.a2 : p.a1;
+    off = s2 ? row * p.lda2 + (c - p.c1) : row * p.lda1 + c;
+  }
+  return ok ? base + off : z;
+}
+
+template <int N>
+LVD_DEV void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// WM x WN waves (WM*WN == 4); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
+template <int MODE, int WM, int WN, int FM, int FN, int STAGES>
+__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const lvd_gemm_params p) {
+  constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
+  constexpr int TILE = (BM + BN) * RCH;                  // uint4 per stage
+  constexpr int AINS = BM / 16, BINS = BN / 16;          // wave-instructions (16 rows x 64 B) per operand tile
+  constexpr int APW = AINS / 4;                          // A instructions per wave (BM is a multiple of 64)
+  constexpr int BPW = (BINS + 3) / 4;                    // B instructions per wave (padded: every wave issues BPW)
+  constexpr int LPS = APW + BPW;                         // glds per wave per stage (uniform -> one vmcnt immediate)
+  __shared__ uint4 lds[STAGES * TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int nb = gridDim.x;
+  int id;
+  {
+    int bid = blockIdx.x;
+    int q = nb >> 3, r = nb & 7;
+    int xcd = bid & 7, idx = bid >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+
+  const int cpos = lane & 3, rsub = lane >> 2;
+  const int csrc = cpos ^ ((rsub >> 2) & 3);  // LDS position (row, cpos) holds source chunk cpos ^ ((row>>2)&3); row&15 == rsub
+
+  RowInfo ar[APW];
+#pragma unroll
+  for (int q = 0; q < APW; ++q) {
+    int m = tm * BM + (wave * APW + q) * 16 + rsub;
+    ar[q].valid = m < p.M;
+    ar[q].off1 = 0; ar[q].off2 = 0; ar[q].oy = 0; ar[q].ox = 0;
+    if (MODE == LVD_A_PLAIN) {
+      ar[q].off1 = (long)m * p.lda1;
+      ar[q].off2 = (long)m * p.lda2;
+    } else if (MODE == LVD_A_CONV3X3 || MODE == LVD_A_CONV3X3_T2) {
+      int plane = p.hout * p.wout;
+      int nimg = m / plane;
+      int rem = m - nimg * plane;
+      ar[q].oy = rem / p.wout;
+      ar[q].ox = rem - ar[q].oy * p.wout;
+      int hs = p.hin, ws = p.win;
+      if (MODE == LVD_A_CONV3X3 && p.upsample) { hs >>= 1; ws >>= 1; }
+      ar[q].off1 = (long)nimg * hs * ws;
+    } else {
+      ar[q].off1 = m;
+      ar[q].oy = (m / p.hw) % p.frames;
+    }
+  }
+  long woff[BPW];
+  bool wvalid[BPW];
+  int bins[BPW];
+#pragma unroll
+  for (int t = 0; t < BPW; ++t) {
+    int b = wave + 4 * t;
+    bool real = b < BINS;
+    bins[t] = real ? b : BINS - 1;  // padding instruction re-stages the last 16 rows (same data, harmless)
+    int n = tn * BN + bins[t] * 16 + rsub;
+    wvalid[t] = n < p.N;
+    woff[t] = (long)n * p.K;
+  }
+
+  auto stage = [&](int kt, int slot) {
+    const int k0 = kt * RBK + csrc * 8;
+    uint4* A = lds + slot * TILE;
+    uint4* B = A + BM * RCH;
+#pragma unroll
+    for (int q = 0; q < APW; ++q) {
+      const lvd_bf16* src = a_src<MODE>(p, ar[q], k0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(A + (wave * APW + q) * 16 * RCH), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < BPW; ++t) {
+      const lvd_bf16* src = (wvalid[t] && k0 < p.K) ? p.w + woff[t] + k0 : reinterpret_cast<const lvd_bf16*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(B + bins[t] * 16 * RCH), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (p.K + RBK - 1) / RBK;
+  // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) stage(s, s);
+
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most (STAGES-2) younger stages are still outstanding
+    wait_vmcnt<(STAGES - 2) * LPS>();
+    __builtin_amdgcn_s_barrier();
+    // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1
+    {
+      int nslot = slot == 0 ? STAGES - 1 : slot - 1;
+      stage(kt + STAGES - 1, nslot);
+    }
+    const uint4* A = lds + slot * TILE;
+    const uint4* B = A + BM * RCH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[FM], bfr[FN];
+      const int c = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        int row = (wm * FM + i) * 32 + l31;
+        af[i] = as_bf16x8(A[row * RCH + (c ^ ((row >> 2) & 3))]);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int row = (wn * FN + j) * 32 + l31;
+        bfr[j] = as_bf16x8(B[row * RCH + (c ^ ((row >> 2) & 3))]);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  }
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  // ---- epilogue: 16 rows x (FN*32) cols per pass through the wave's private LDS slice
+  constexpr int WNC = FN * 32;
+  constexpr int SLICE = STAGES * TILE;  // floats per wave = (STAGES*TILE*16 B) / 4 waves / 4 B
+  static_assert(SLICE >= 16 * WNC, "LDS slice too small for a 16-row epilogue pass");
+  float* S = reinterpret_cast<float*>(lds) + wave * SLICE;
+  const int mbase = tm * BM + wm * FM * 32;
+  const int nbase = tn * BN + wn * WNC;
+#pragma unroll
+  for (int ps = 0; ps < 2 * FM; ++ps) {
+    const int i = ps >> 1, eh = (ps & 1) * 8;
+    if (ps > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        int rowl = (e8 & 3) + 8 * (e8 >> 2) + 4 * hi;
+        S[rowl * WNC + j * 32 + l31] = acc[i][j][eh + e8];
+      }
+    __syncthreads();
+    const int mrow0 = mbase + i * 32 + (ps & 1) * 16;
+    if (p.act == LVD_ACT_GEGLU) {
+      lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
+      constexpr int QPR = WNC / 8;  // output quads per row (WNC/2 outputs)
+#pragma unroll
+      for (int it = 0; it < (16 * QPR + 63) / 64; ++it) {
+        int idx = it * 64 + lane;
+        if (idx >= 16 * QPR) continue;
+        int row = idx / QPR, oq = idx - row * QPR;
+        int blk = oq >> 3, cq = oq & 7;
+        int m = mrow0 + row;
+        int n = nbase + blk * 64 + cq * 4;
+        if (m >= p.M || n + 32 >= p.N) continue;
+        f32x4 h = *reinterpret_cast<const f32x4*>(&S[row * WNC + blk * 64 + cq * 4]);
+        f32x4 g = *reinterpret_cast<const f32x4*>(&S[row * WNC + blk * 64 + 32 + cq * 4]);
+        if (p.bias) {
+          h += *reinterpret_cast<const f32x4*>(p.bias + n);
+          g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+        }
+        int oc = (nbase >> 1) + blk * 32 + cq * 4;
+        uint2 o;
+        o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
+        o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+        stg8(out + (long)m * p.ldc + oc, o);
+      }
+      continue;
+    }
+    constexpr int QPR = WNC / 4;
+#pragma unroll
+    for (int it = 0; it < (16 * QPR + 63) / 64; ++it) {
+      int idx = it * 64 + lane;
+      if (idx >= 16 * QPR) continue;
+      int row = idx / QPR, cq = idx - row * QPR;
+      int m = mrow0 + row;
+      int n = nbase + cq * 4;
+      if (m >= p.M || n >= p.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * WNC + cq * 4]);
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
+      v *= p.alpha;
+      if (p.res) {
+        uint2 r = ldg8(p.res + (long)m * p.ldres + n);
+        v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+      }
+      if (p.out_fp32) {
+        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+      } else {
+        lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+        if (p.accumulate) {
+          uint2 r = ldg8(o);
+          v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+        }
+        uint2 w;
+        w.x = pack2bf(v[0], v[1]);
+        w.y = pack2bf(v[2], v[3]);
+        stg8(o, w);
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int FM, int FN, int STAGES>
+int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
+  constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
+  int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
+  dim3 grid(tiles), block(256);
+  switch (p->mode) {
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
+    default: return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// geometry: 0 = 128x128 (3 stages), 1 = 128x128 (4 stages), 2 = 256x160 (3 stages), 3 = 256x128 (3 stages)
+int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (geometry) {
+    case 0: return launch_ring<2, 2, 2, 2, 3>(p, s);
+    case 1: return launch_ring<2, 2, 2, 2, 4>(p, s);
+    case 2: return launch_ring<4, 1, 2, 5, 3>(p, s);
+    case 3: return launch_ring<4, 1, 2, 4, 3>(p, s);
+    default: return 1;
+  }
+}
