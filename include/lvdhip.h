@@ -49,6 +49,14 @@ enum {
   LVD_A_CONV3X3_T2 = 3  /* transposed (dgrad of the stride-2 pad-1 conv): K = 9*Cin */
 };
 enum { LVD_ACT_NONE = 0, LVD_ACT_GEGLU = 1 };
+/* tile geometries (all produce identical results up to fp32 summation order inside a K tile) */
+enum {
+  LVD_GEMM_V_REG32 = 1,     /* 128x128x32 register-staged, 4 workgroups/CU */
+  LVD_GEMM_V_RING128 = 5,   /* 128x128x32 LDS-DMA ring (3 stages), 3 workgroups/CU */
+  LVD_GEMM_V_RING256N = 9,  /* 256x160 / 256x128 LDS-DMA ring, 4 waves */
+  LVD_GEMM_V_REG64 = 10,    /* 128x128x64 register-staged, 2 workgroups/CU */
+  LVD_GEMM_V_RING256W = 11  /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
+};
 
 typedef struct {
   const lvd_bf16* a1;      /* first A source  [rows, lda1] */
@@ -73,6 +81,7 @@ typedef struct {
   int32_t out_fp32;
   float alpha;             /* out = res + alpha * (acc + bias + rowbias) */
   int32_t accumulate;      /* 1: out += (bf16 read-modify-write; used for gradient accumulation) */
+  int32_t variant;         /* 0 = library heuristic; >0 pins a tile geometry (LVD_GEMM_V_*), used by the host autotuner */
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);

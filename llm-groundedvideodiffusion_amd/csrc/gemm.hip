@@ -311,7 +311,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
     const char* e = getenv("LVD_GEMM_VARIANT");  // developer knob for A/B runs (tools/gemm_bench.py)
     variant = e ? atoi(e) : 0;
   }
-  int v = variant;
+  int v = p->variant ? p->variant : variant;
   if (v == 0) {
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_variants.txt):
     //   under-filled grids            -> 128x128x64 register-staged (fewest, longest tiles)
@@ -323,6 +323,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   }
   int rc;
   if (v >= 5 && v <= 8) rc = lvd_gemm_ring_dispatch(p, stream, v - 5);
+  else if (v == 11) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
   else if (v == 9) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
   else if (v == 1) rc = launch_gemm<32, 3>(p, grid, s);
   else if (v == 2) rc = launch_gemm<32, 4>(p, grid, s);

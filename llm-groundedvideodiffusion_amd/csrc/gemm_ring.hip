@@ -100,14 +100,16 @@ LVD_DEV void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// WM x WN waves (WM*WN == 4); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
+// WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
 template <int MODE, int WM, int WN, int FM, int FN, int STAGES>
-__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const lvd_gemm_params p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
+  constexpr int NW = WM * WN;
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   constexpr int TILE = (BM + BN) * RCH;                  // uint4 per stage
   constexpr int AINS = BM / 16, BINS = BN / 16;          // wave-instructions (16 rows x 64 B) per operand tile
-  constexpr int APW = AINS / 4;                          // A instructions per wave (BM is a multiple of 64)
-  constexpr int BPW = (BINS + 3) / 4;                    // B instructions per wave (padded: every wave issues BPW)
+  constexpr int APW = AINS / NW;                         // A instructions per wave (BM is a multiple of 16*NW)
+  constexpr int BPW = (BINS + NW - 1) / NW;              // B instructions per wave (padded: every wave issues BPW)
+  static_assert(AINS % NW == 0, "BM must be a multiple of 16 * waves");
   constexpr int LPS = APW + BPW;                         // glds per wave per stage (uniform -> one vmcnt immediate)
   __shared__ uint4 lds[STAGES * TILE];
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const lvd_gemm_params
   int bins[BPW];
 #pragma unroll
   for (int t = 0; t < BPW; ++t) {
-    int b = wave + 4 * t;
+    int b = wave + NW * t;
     bool real = b < BINS;
     bins[t] = real ? b : BINS - 1;  // padding instruction re-stages the last 16 rows (same data, harmless)
     int n = tn * BN + bins[t] * 16 + rsub;
@@ -226,92 +228,76 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(const lvd_gemm_params
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = token row
     }
     slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
   wait_vmcnt<0>();
-  __syncthreads();
 
-  // ---- epilogue: 16 rows x (FN*32) cols per pass through the wave's private LDS slice
-  constexpr int WNC = FN * 32;
-  constexpr int SLICE = STAGES * TILE;  // floats per wave = (STAGES*TILE*16 B) / 4 waves / 4 B
-  static_assert(SLICE >= 16 * WNC, "LDS slice too small for a 16-row epilogue pass");
-  float* S = reinterpret_cast<float*>(lds) + wave * SLICE;
+  // ---- epilogue straight from registers.  The MFMAs were issued as D = W_frag · X_frag^T, so lane (l31) owns token
+  // row m and every 4 consecutive accumulator registers are 4 consecutive output channels: bias / temb row-bias /
+  // gate / residual / GEGLU are applied on 8-byte row-contiguous vectors with no LDS round trip and no barrier.
   const int mbase = tm * BM + wm * FM * 32;
-  const int nbase = tn * BN + wn * WNC;
+  const int nbase = tn * BN + wn * FN * 32;
 #pragma unroll
-  for (int ps = 0; ps < 2 * FM; ++ps) {
-    const int i = ps >> 1, eh = (ps & 1) * 8;
-    if (ps > 0) __syncthreads();
+  for (int i = 0; i < FM; ++i) {
+    const int m = mbase + i * 32 + l31;
+    if (m >= p.M) continue;
+    if (p.act == LVD_ACT_GEGLU) {
+      lvd_bf16* orow = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc;
+#pragma unroll
+      for (int b = 0; b < FN / 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nbase + b * 64 + 8 * q + 4 * hi;  // hidden column in the interleaved W'; gate = n + 32
+          if (n + 32 >= p.N) continue;
+          f32x4 h, g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
+          if (p.bias) {
+            h += *reinterpret_cast<const f32x4*>(p.bias + n);
+            g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+          }
+          uint2 o;
+          o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
+          o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+          stg8(orow + (nbase >> 1) + b * 32 + 8 * q + 4 * hi, o);
+        }
+      continue;
+    }
+    const float* rb = p.rowbias ? p.rowbias + (long)(m / p.rows_per_sample) * p.N : nullptr;
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int e8 = 0; e8 < 8; ++e8) {
-        int rowl = (e8 & 3) + 8 * (e8 >> 2) + 4 * hi;
-        S[rowl * WNC + j * 32 + l31] = acc[i][j][eh + e8];
-      }
-    __syncthreads();
-    const int mrow0 = mbase + i * 32 + (ps & 1) * 16;
-    if (p.act == LVD_ACT_GEGLU) {
-      lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
-      constexpr int QPR = WNC / 8;  // output quads per row (WNC/2 outputs)
+      for (int q = 0; q < 4; ++q) {
+        const int n = nbase + j * 32 + 8 * q + 4 * hi;
+        if (n >= p.N) continue;
+        f32x4 v;
 #pragma unroll
-      for (int it = 0; it < (16 * QPR + 63) / 64; ++it) {
-        int idx = it * 64 + lane;
-        if (idx >= 16 * QPR) continue;
-        int row = idx / QPR, oq = idx - row * QPR;
-        int blk = oq >> 3, cq = oq & 7;
-        int m = mrow0 + row;
-        int n = nbase + blk * 64 + cq * 4;
-        if (m >= p.M || n + 32 >= p.N) continue;
-        f32x4 h = *reinterpret_cast<const f32x4*>(&S[row * WNC + blk * 64 + cq * 4]);
-        f32x4 g = *reinterpret_cast<const f32x4*>(&S[row * WNC + blk * 64 + 32 + cq * 4]);
-        if (p.bias) {
-          h += *reinterpret_cast<const f32x4*>(p.bias + n);
-          g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-        }
-        int oc = (nbase >> 1) + blk * 32 + cq * 4;
-        uint2 o;
-        o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-        o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
-        stg8(out + (long)m * p.ldc + oc, o);
-      }
-      continue;
-    }
-    constexpr int QPR = WNC / 4;
-#pragma unroll
-    for (int it = 0; it < (16 * QPR + 63) / 64; ++it) {
-      int idx = it * 64 + lane;
-      if (idx >= 16 * QPR) continue;
-      int row = idx / QPR, cq = idx - row * QPR;
-      int m = mrow0 + row;
-      int n = nbase + cq * 4;
-      if (m >= p.M || n >= p.N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * WNC + cq * 4]);
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
-      v *= p.alpha;
-      if (p.res) {
-        uint2 r = ldg8(p.res + (long)m * p.ldres + n);
-        v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
-      }
-      if (p.out_fp32) {
-        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
-        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
-        *reinterpret_cast<f32x4*>(o) = v;
-      } else {
-        lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
-        if (p.accumulate) {
-          uint2 r = ldg8(o);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+        v *= p.alpha;
+        if (p.res) {
+          uint2 r = ldg8(p.res + (long)m * p.ldres + n);
           v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
         }
-        uint2 w;
-        w.x = pack2bf(v[0], v[1]);
-        w.y = pack2bf(v[2], v[3]);
-        stg8(o, w);
+        if (p.out_fp32) {
+          float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+          lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+          if (p.accumulate) {
+            uint2 r = ldg8(o);
+            v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+          }
+          uint2 w;
+          w.x = pack2bf(v[0], v[1]);
+          w.y = pack2bf(v[2], v[3]);
+          stg8(o, w);
+        }
       }
-    }
   }
 }
 
@@ -319,7 +305,7 @@ template <int WM, int WN, int FM, int FN, int STAGES>
 int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
-  dim3 grid(tiles), block(256);
+  dim3 grid(tiles), block(64 * WM * WN);
   switch (p->mode) {
     case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
     case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
@@ -332,7 +318,8 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
 
 }  // namespace
 
-// geometry: 0 = 128x128 (3 stages), 1 = 128x128 (4 stages), 2 = 256x160 (3 stages), 3 = 256x128 (3 stages)
+// geometry: 0 = 128x128 (3 stages), 1 = 128x128 (4 stages), 2 = 256x160 (3 stages), 3 = 256x128 (3 stages),
+//           4 = 256x320 8 waves (3 stages), 5 = 256x256 8 waves (3 stages)
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
   hipStream_t s = (hipStream_t)stream;
   switch (geometry) {
@@ -340,6 +327,8 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
     case 1: return launch_ring<2, 2, 2, 2, 4>(p, s);
     case 2: return launch_ring<4, 1, 2, 5, 3>(p, s);
     case 3: return launch_ring<4, 1, 2, 4, 3>(p, s);
+    case 4: return launch_ring<4, 2, 2, 5, 3>(p, s);
+    case 5: return launch_ring<4, 2, 2, 4, 3>(p, s);
     default: return 1;
   }
 }

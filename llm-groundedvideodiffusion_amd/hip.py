@@ -26,7 +26,7 @@ class GemmParams(C.Structure):
         ("lda1", i32), ("lda2", i32), ("c1", i32), ("cin", i32), ("mode", i32),
         ("hin", i32), ("win", i32), ("hout", i32), ("wout", i32), ("stride", i32), ("upsample", i32),
         ("frames", i32), ("hw", i32), ("rows_per_sample", i32), ("ldres", i32), ("ldc", i32),
-        ("act", i32), ("out_fp32", i32), ("alpha", f32), ("accumulate", i32),
+        ("act", i32), ("out_fp32", i32), ("alpha", f32), ("accumulate", i32), ("variant", i32),
     ]
 
 

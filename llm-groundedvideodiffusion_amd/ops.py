@@ -51,9 +51,53 @@ class ConvGeom:
     upsample: int = 0
 
 
+# ------------------------------------------------------------------ GEMM autotuner
+# The GEMM library ships several tile geometries (include/lvdhip.h LVD_GEMM_V_*).  Which one wins depends on
+# (M, N, K, loader): short-K linears favour many small workgroups, long-K convs the LDS-DMA ring, and the
+# 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
+# candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
+GEMM_CANDIDATES = (10, 1, 5, 9, 11)
+_gemm_choice = {}
+_autotune = {"enabled": True, "min_flops": 2e9}
+
+
+def set_gemm_autotune(enabled: bool):
+    _autotune["enabled"] = bool(enabled)
+
+
+def gemm_autotune_table():
+    return dict(_gemm_choice)
+
+
+def _launch_gemm(p):
+    hip.check(hip.lib().lvdhip_gemm(C.byref(p), _stream()), "gemm")
+
+
+def _tune_gemm(p, key, out):
+    scratch = torch.empty((out.shape[0], p.ldc), dtype=out.dtype, device=out.device)  # same row stride as the real output
+    saved_out, saved_acc = p.out, p.accumulate
+    p.out, p.accumulate = scratch.data_ptr(), 0
+    best, best_t = 0, float("inf")
+    for v in GEMM_CANDIDATES:
+        p.variant = v
+        _launch_gemm(p)  # warm-up (also instruction-cache / L2)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(3):
+            _launch_gemm(p)
+        e.record()
+        e.synchronize()
+        t = s.elapsed_time(e)
+        if t < best_t:
+            best, best_t = v, t
+    p.out, p.accumulate = saved_out, saved_acc
+    _gemm_choice[key] = best
+    return best
+
+
 def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sample=0, res=None, out=None,
          mode=A_PLAIN, conv: Optional[ConvGeom] = None, frames=0, hw=0, cin=None, act=ACT_NONE, out_fp32=False,
-         alpha=1.0, accumulate=False, m=None):
+         alpha=1.0, accumulate=False, m=None, variant=0):
     """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`."""
     _chk_bf16(a1, a2, w, res)
     _chk_f32(bias, rowbias)
@@ -83,7 +127,11 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     p.ldres = _ld(res) if res is not None else 0
     p.ldc = _ld(out)
     p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
-    hip.check(hip.lib().lvdhip_gemm(C.byref(p), _stream()), "gemm")
+    if variant == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"] and not torch.cuda.is_current_stream_capturing():
+        key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample) if conv is not None else None, int(out_fp32))
+        variant = _gemm_choice.get(key) or _tune_gemm(p, key, out)
+    p.variant = variant
+    _launch_gemm(p)
     return out
 
 

@@ -333,3 +333,45 @@ def test_elementwise():
     close(ops.silu(x), F.silu(x.float()), 6e-3, "silu")
     v = rnd(1000, seed=6)
     assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
+
+
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11])
+def test_gemm_every_tile_geometry(variant):
+    """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
+    epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
+    M, N, K, rps = 700, 320, 648, 100
+    a, w = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4, scale=0.05))
+    bias, rowb, res = rnd(N, seed=5), rnd(M // rps, N, seed=6), bf(rnd(M, N, seed=7))
+    ref = res.float() + 0.5 * (a.float() @ w.float().T + bias + rowb.repeat_interleave(rps, 0))
+    close(ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, alpha=0.5, variant=variant), ref, 6e-3, f"v{variant} epilogue")
+    a1, a2 = bf(rnd(M, 192, seed=1)), bf(rnd(M, 128, seed=2))
+    w2 = bf(rnd(160, 320, seed=3, scale=0.05))
+    close(ops.gemm(a1, w2, a2=a2, variant=variant), torch.cat([a1, a2], 1).float() @ w2.float().T, 6e-3, f"v{variant} concat")
+    from lvd_amd.weights import interleave_geglu, pack_conv3x3_dgrad_t2
+    wg, bg = bf(rnd(512, 128, seed=2, scale=0.08)), rnd(512, seed=3)
+    ag = bf(rnd(300, 128, seed=1))
+    proj = ag.float() @ wg.float().T + bg
+    wi, bi = interleave_geglu(wg, bg)
+    close(ops.gemm(ag, wi, bias=bi, act=ops.ACT_GEGLU, variant=variant), proj[:, :256] * F.gelu(proj[:, 256:]), 6e-3, f"v{variant} geglu")
+    n, cin, cout, h, wd = 3, 64, 96, 10, 18
+    x = bf(rnd(n, cin, h, wd, seed=1)).float()
+    wt = bf(conv_w(cout, cin, 2)).float()
+    for stride, up in ((1, 0), (2, 0), (1, 1)):
+        xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+        refc = F.conv2d(xin, wt, None, stride=stride, padding=1)
+        out = ops.gemm(bf(to_tokens(x)), pack_conv(wt), mode=ops.A_CONV3X3, variant=variant,
+                       conv=ops.ConvGeom(xin.shape[2], xin.shape[3], refc.shape[2], refc.shape[3], stride, up))
+        close(from_tokens(out, n, refc.shape[2], refc.shape[3]), refc, 6e-3, f"v{variant} conv s{stride} up{up}")
+    y2 = F.conv2d(x.requires_grad_(True), wt, None, stride=2, padding=1)
+    dy = bf(rnd(*y2.shape, seed=3)).float()
+    (gref,) = torch.autograd.grad(y2, x, dy)
+    out = ops.gemm(bf(to_tokens(dy)), pack_conv3x3_dgrad_t2(wt), mode=ops.A_CONV3X3_T2, conv=ops.ConvGeom(y2.shape[2], y2.shape[3], h, wd),
+                   m=n * h * wd, variant=variant)
+    close(from_tokens(out, n, h, wd), gref, 6e-3, f"v{variant} conv T2")
+    Bt, Fr, hw, c = 2, 5, 12, 64
+    xt = bf(rnd(Bt * Fr * hw, c, seed=1))
+    wtc = bf(rnd(c, c, 3, seed=2, scale=0.05)).float()
+    x5 = xt.float().reshape(Bt, Fr, hw, c).permute(0, 3, 1, 2)[..., None]
+    reft = F.conv3d(x5, wtc[..., None, None], None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(Bt * Fr * hw, c)
+    out = ops.gemm(xt, bf(wtc.permute(0, 2, 1).reshape(c, 3 * c).contiguous()), mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=variant)
+    close(out, reft, 6e-3, f"v{variant} tconv")
