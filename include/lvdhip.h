@@ -55,7 +55,8 @@ enum {
   LVD_GEMM_V_RING128 = 5,   /* 128x128x32 LDS-DMA ring (3 stages), 3 workgroups/CU */
   LVD_GEMM_V_RING256N = 9,  /* 256x160 / 256x128 LDS-DMA ring, 4 waves */
   LVD_GEMM_V_REG64 = 10,    /* 128x128x64 register-staged, 2 workgroups/CU */
-  LVD_GEMM_V_RING256W = 11  /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
+  LVD_GEMM_V_RING256W = 11, /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
+  LVD_GEMM_V_RING256K64 = 14 /* 256x256x64 LDS-DMA double buffer, 8 waves */
 };
 
 typedef struct {

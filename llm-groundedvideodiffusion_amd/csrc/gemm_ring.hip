@@ -19,7 +19,6 @@
 
 namespace {
 
-constexpr int RBK = 32, RCH = 4;  // K depth per stage, 16-byte chunks per row
 
 __device__ uint4 g_zero_page[4];
 
@@ -101,15 +100,17 @@ LVD_DEV void wait_vmcnt() {
 }
 
 // WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
-template <int MODE, int WM, int WN, int FM, int FN, int STAGES>
+template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
   constexpr int NW = WM * WN;
+  constexpr int RCH = RBK / 8;                            // 16-byte chunks per tile row (4: 64 B rows, 8: full 128 B lines)
+  constexpr int RPI = 64 / RCH;                          // tile rows covered by one wave-wide glds instruction
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   constexpr int TILE = (BM + BN) * RCH;                  // uint4 per stage
-  constexpr int AINS = BM / 16, BINS = BN / 16;          // wave-instructions (16 rows x 64 B) per operand tile
+  constexpr int AINS = BM / RPI, BINS = BN / RPI;        // wave-instructions per operand tile
   constexpr int APW = AINS / NW;                         // A instructions per wave (BM is a multiple of 16*NW)
   constexpr int BPW = (BINS + NW - 1) / NW;              // B instructions per wave (padded: every wave issues BPW)
-  static_assert(AINS % NW == 0, "BM must be a multiple of 16 * waves");
+  static_assert(AINS % NW == 0, "BM must be a multiple of RPI * waves");
   constexpr int LPS = APW + BPW;                         // glds per wave per stage (uniform -> one vmcnt immediate)
   __shared__ uint4 lds[STAGES * TILE];
 
@@ -130,13 +131,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tm = id / tiles_n, tn = id - tm * tiles_n;
 
-  const int cpos = lane & 3, rsub = lane >> 2;
-  const int csrc = cpos ^ ((rsub >> 2) & 3);  // LDS position (row, cpos) holds source chunk cpos ^ ((row>>2)&3); row&15 == rsub
+  // LDS image is lane-linear per instruction (row = rsub, position = cpos); the bank-conflict swizzle is applied to the
+  // SOURCE chunk: RCH=4: pos ^ ((row>>2)&3), RCH=8: pos ^ ((row>>1)&7)  (row parity of 8-row instructions enters via bit 2)
+  const int cpos = lane % RCH, rsub = lane / RCH;
+  auto swz = [](int row, int c) { return RCH == 4 ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 1) & 7)); };
 
   RowInfo ar[APW];
 #pragma unroll
   for (int q = 0; q < APW; ++q) {
-    int m = tm * BM + (wave * APW + q) * 16 + rsub;
+    int m = tm * BM + (wave * APW + q) * RPI + rsub;
     ar[q].valid = m < p.M;
     ar[q].off1 = 0; ar[q].off2 = 0; ar[q].oy = 0; ar[q].ox = 0;
     if (MODE == LVD_A_PLAIN) {
@@ -164,24 +167,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     int b = wave + NW * t;
     bool real = b < BINS;
     bins[t] = real ? b : BINS - 1;  // padding instruction re-stages the last 16 rows (same data, harmless)
-    int n = tn * BN + bins[t] * 16 + rsub;
+    int n = tn * BN + bins[t] * RPI + rsub;
     wvalid[t] = n < p.N;
     woff[t] = (long)n * p.K;
   }
 
   auto stage = [&](int kt, int slot) {
-    const int k0 = kt * RBK + csrc * 8;
     uint4* A = lds + slot * TILE;
     uint4* B = A + BM * RCH;
 #pragma unroll
     for (int q = 0; q < APW; ++q) {
+      const int k0 = kt * RBK + swz((wave * APW + q) * RPI + rsub, cpos) * 8;
       const lvd_bf16* src = a_src<MODE>(p, ar[q], k0);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(A + (wave * APW + q) * 16 * RCH), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(A + (wave * APW + q) * RPI * RCH), 16, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < BPW; ++t) {
+      const int k0 = kt * RBK + swz(bins[t] * RPI + rsub, cpos) * 8;
       const lvd_bf16* src = (wvalid[t] && k0 < p.K) ? p.w + woff[t] + k0 : reinterpret_cast<const lvd_bf16*>(g_zero_page);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(B + bins[t] * 16 * RCH), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(B + bins[t] * RPI * RCH), 16, 0, 0);
     }
   };
 
@@ -211,18 +215,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     const uint4* A = lds + slot * TILE;
     const uint4* B = A + BM * RCH;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < RBK / 16; ++ks) {
       bf16x8 af[FM], bfr[FN];
       const int c = ks * 2 + hi;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         int row = (wm * FM + i) * 32 + l31;
-        af[i] = as_bf16x8(A[row * RCH + (c ^ ((row >> 2) & 3))]);
+        af[i] = as_bf16x8(A[row * RCH + swz(row, c)]);
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         int row = (wn * FN + j) * 32 + l31;
-        bfr[j] = as_bf16x8(B[row * RCH + (c ^ ((row >> 2) & 3))]);
+        bfr[j] = as_bf16x8(B[row * RCH + swz(row, c)]);
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -301,16 +305,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   }
 }
 
-template <int WM, int WN, int FM, int FN, int STAGES>
+template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32>
 int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   dim3 grid(tiles), block(64 * WM * WN);
   switch (p->mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
-    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES>), grid, block, 0, s, *p); break;
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
     default: return 1;
   }
   return 0;
@@ -319,7 +323,7 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
 }  // namespace
 
 // geometry: 0 = 128x128 (3 stages), 1 = 128x128 (4 stages), 2 = 256x160 (3 stages), 3 = 256x128 (3 stages),
-//           4 = 256x320 8 waves (3 stages), 5 = 256x256 8 waves (3 stages)
+//           4 = 256x320 8 waves (3 stages), 5 = 256x256 8 waves (3 stages), 8 = 256x256x64 8 waves (2 stages)
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
   hipStream_t s = (hipStream_t)stream;
   switch (geometry) {
@@ -329,6 +333,7 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
     case 3: return launch_ring<4, 1, 2, 4, 3>(p, s);
     case 4: return launch_ring<4, 2, 2, 5, 3>(p, s);
     case 5: return launch_ring<4, 2, 2, 4, 3>(p, s);
+    case 8: return launch_ring<4, 2, 2, 4, 2, 64>(p, s);
     default: return 1;
   }
 }

@@ -6,6 +6,8 @@ import lvd_amd
 from lvd_amd import ops
 
 dev = "cuda"
+if os.environ.get("LVD_GEMM_VARIANT"):
+    ops.set_gemm_autotune(False)
 def rnd(*s): return torch.randn(*s, device=dev).bfloat16()
 
 HW0, F, B = 2880, 24, 2
