@@ -1,0 +1,70 @@
+"""`HipAttnProcessor`: the reference's per-op plug-in (`Attention.set_processor`,
+/root/reference/models/attention_processor.py:167-180) backed by the HIP kernels.
+
+Same call contract as AttnProcessor.__call__ (:432-449, including the `return_attntion_probs` spelling): given an
+`Attention`-like module (`.to_q/.to_k/.to_v/.to_out[0]` Linear layers, `.heads`), hidden states (B, L, C) and optional
+encoder states (B, T, D) it returns the attended hidden states; when the key is listed in `save_keys` the probabilities
+(B, heads, L, T) are stored in `save_attn_to_dict[tuple(attn_key)]`.  Constraints of the kernels: CUDA tensors, head
+dim 64, no attention mask (the reference never passes one on this path, unet_3d_blocks.py:406 TODO)."""
+import torch
+
+from .. import ops
+
+
+def _w(linear):
+    cache = getattr(linear, "_lvd_packed", None)
+    if cache is None or cache[0] is not linear.weight:
+        w = linear.weight.detach().to(torch.bfloat16).contiguous()
+        b = None if linear.bias is None else linear.bias.detach().to(torch.float32).contiguous()
+        cache = (linear.weight, w, b)
+        linear._lvd_packed = cache
+    return cache[1], cache[2]
+
+
+class HipAttnProcessor:
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, return_attntion_probs=False,
+                 attn_key=None, attn_process_fn=None, return_cond_ca_only=False, return_token_ca_only=None,
+                 offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None, enable_flash_attn=True,
+                 cross_attn_save_hidden_states=False):
+        if attention_mask is not None or attn_process_fn is not None:
+            raise NotImplementedError("attention_mask / attn_process_fn are not supported by the fused HIP attention")
+        if hidden_states.dim() != 3 or not hidden_states.is_cuda:
+            raise ValueError("HipAttnProcessor expects CUDA hidden states of shape (batch, tokens, channels)")
+        B, L, Cc = hidden_states.shape
+        heads = attn.heads
+        if Cc != heads * 64:
+            raise NotImplementedError(f"head_dim must be 64 (got channels={Cc}, heads={heads})")
+        cross = encoder_hidden_states is not None
+        x = hidden_states.reshape(B * L, Cc).to(torch.bfloat16).contiguous()
+        ctx = x if not cross else encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1]).to(torch.bfloat16).contiguous()
+        T = L if not cross else encoder_hidden_states.shape[1]
+        wq, _ = _w(attn.to_q)
+        wk, _ = _w(attn.to_k)
+        wv, _ = _w(attn.to_v)
+        wo, bo = _w(attn.to_out[0])
+        q, k, v = ops.gemm(x, wq), ops.gemm(ctx, wk), ops.gemm(ctx, wv)
+        o = torch.empty_like(q)
+        ops.attention_fwd(q, k, v, o, samples=B, heads=heads, sq=L, skv=T, qmap=ops.RowMap(1, L, 0, 1), kvmap=ops.RowMap(1, T, 0, 1),
+                          scale=float(getattr(attn, "scale", 0.125)))
+        out = ops.gemm(o, wo, bias=bo).reshape(B, L, Cc).to(hidden_states.dtype)
+        want = return_attntion_probs or (save_attn_to_dict is not None and (save_keys is None or tuple(attn_key) in save_keys))
+        if cross and want:
+            # probabilities are only materialised on request (visualisation / external losses); fp32 like the loss maths
+            qf = q.float().reshape(B, L, heads, 64).permute(0, 2, 1, 3)
+            kf = k.float().reshape(B, T, heads, 64).permute(0, 2, 3, 1)
+            probs = (qf @ kf * float(getattr(attn, "scale", 0.125))).softmax(-1)
+            if return_token_ca_only is not None:
+                probs = probs[..., return_token_ca_only:return_token_ca_only + 1] if isinstance(return_token_ca_only, int) else probs[..., return_token_ca_only]
+            if return_cond_ca_only:
+                assert B % 2 == 0, f"Samples are not in pairs: {B} samples"
+                probs = probs[B // 2:]
+            if offload_cross_attn_to_cpu:
+                probs = probs.cpu()
+            if save_attn_to_dict is not None and save_keys is not None and tuple(attn_key) in save_keys:
+                save_attn_to_dict[tuple(attn_key)] = probs
+            if return_attntion_probs:
+                return out, probs
+        return out
+
+
+AttentionProcessor = HipAttnProcessor
