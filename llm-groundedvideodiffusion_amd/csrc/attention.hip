@@ -14,6 +14,7 @@
 // text cross-attention (77 keys), temporal attention (rows HW apart — the reference's
 // (B·F,HW,C)<->(B·HW,F,C) permutes, models/transformer_temporal.py:154-156,175-182, are fused away)
 // and the GLIGEN fuser (second key/value segment of 30 grounding tokens, models/attention.py:51-57).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -24,6 +25,7 @@ LVD_DEV long base_row(int s, int ninner, int os, int is) {
   return (long)so * os + (long)si * is;
 }
 
+constexpr float RESCALE_THR = 5.f;  // log2 units: deferred running-max update (see the softmax blocks)
 constexpr int VT_PITCH = 18;  // dwords per d-row of the transposed V tile (16 key pairs + 2 pad)
 
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
@@ -97,26 +99,34 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
     }
     __syncthreads();
 
-    // ---- online softmax (lane-local over this lane's 16 keys + partner half)
+    // ---- online softmax (lane-local over this lane's 16 keys + partner half).  The running max is only raised when
+    // some query's tile maximum exceeds it by more than 2^RESCALE_THR (exact: p stays <= 2^THR, l and O share the scale)
     float pv[16];
     float tmax = -1e30f;
+    const bool last = (kt + 1) * 32 >= skv_tot;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      float v = (kidx < skv_tot) ? st[e] * sc : -1e30f;
+      float v = st[e] * sc;
+      if (last) {
+        int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        v = (kidx < skv_tot) ? v : -1e30f;
+      }
       pv[e] = v;
       tmax = fmaxf(tmax, v);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    float mn = fmaxf(m, tmax);
-    float alpha = exp2f(m - mn);
+    if (__any(tmax > m + RESCALE_THR)) {
+      float mn = fmaxf(m, tmax);
+      float alpha = fast_exp2(m - mn);
+      lsum *= alpha;
+      m = mn;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    }
     float rs = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { pv[e] = exp2f(pv[e] - mn); rs += pv[e]; }
-    lsum = lsum * alpha + rs;
-    m = mn;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    for (int e = 0; e < 16; ++e) { pv[e] = fast_exp2(pv[e] - m); rs += pv[e]; }
+    lsum += rs;
 
     // ---- O^T += V^T · P^T
 #pragma unroll
@@ -165,6 +175,164 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: 4 waves share every K/V tile through LDS (self-attention over long sequences: 2880 / 720 keys at the upper UNet
+// levels streams K/V once per 128 queries instead of once per 32).  64-key tiles, register-prefetched double buffer:
+//   K tile  [64 keys][8 x 16 B] with the XOR chunk swizzle of the GEMM A tile (conflict-free ds_read_b128 fragments)
+//   V tile  transposed [64 d][32 key pairs (+2 pad)] written as packed key pairs, read as two ds_read_b64 per fragment
+constexpr int V2_VP = 34;
+
+__global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const lvd_attn_params p) {
+  __shared__ uint4 k_lds[2][64 * 8];
+  __shared__ uint32_t vt_lds[2][64 * V2_VP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.sq + 127) >> 7;
+  const int s = blockIdx.x / nqt, qt = blockIdx.x - s * nqt, h = blockIdx.y;
+  const long qbase = base_row(s, p.q_ninner, p.q_os, p.q_is);
+  const long kvbase = base_row(s, p.kv_ninner, p.kv_os, p.kv_is);
+  const int skv = p.skv;
+
+  const int qi = qt * 128 + wave * 32 + l31;
+  const int qic = min(qi, p.sq - 1);
+  bf16x8 qf[4];
+  {
+    const lvd_bf16* qp = p.q + (qbase + (long)qic * p.q_step) * p.ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+  float m = -1e30f, lsum = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;
+
+  // staging roles
+  const int kr = tid >> 3, kc = tid & 7;   // K: rows kr, kr+32; 16-byte chunk kc
+  const int vj = tid & 31, vdc = tid >> 5; // V: keys 2vj, 2vj+1; d = 8*vdc..8*vdc+7
+  uint4 rk[2], rv[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = min(kt * 64 + kr + 32 * i, skv - 1);
+      rk[i] = ldg16(p.k + (kvbase + (long)key * p.kv_step) * p.ldk + h * 64 + kc * 8);
+      int vkey = min(kt * 64 + 2 * vj + i, skv - 1);
+      rv[i] = ldg16(p.v + (kvbase + (long)vkey * p.kv_step) * p.ldv + h * 64 + vdc * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = kr + 32 * i;
+      k_lds[buf][row * 8 + (kc ^ ((row >> 1) & 7))] = rk[i];
+    }
+    uint32_t aw[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w}, bw[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+    uint32_t* vt = vt_lds[buf];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      vt[(vdc * 8 + 2 * e) * V2_VP + vj] = (aw[e] & 0xffffu) | (bw[e] << 16);
+      vt[(vdc * 8 + 2 * e + 1) * V2_VP + vj] = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
+    }
+  };
+
+  const int nt = (skv + 63) >> 6;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nt) load_tile(kt + 1);
+    const uint4* kl = k_lds[buf];
+    const uint32_t* vt = vt_lds[buf];
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
+      const int row = kb * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 kf = as_bf16x8(kl[row * 8 + ((ks * 2 + hi) ^ ((row >> 1) & 7))]);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+    float pv[2][16];
+    float tmax = -1e30f;
+    const bool last = kt + 1 == nt;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = st[kb][e] * sc;
+        if (last) {
+          int kidx = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          v = (kidx < skv) ? v : -1e30f;
+        }
+        pv[kb][e] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (__any(tmax > m + RESCALE_THR)) {
+      float mn = fmaxf(m, tmax);
+      float alpha = fast_exp2(m - mn);
+      lsum *= alpha;
+      m = mn;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { pv[kb][e] = fast_exp2(pv[kb][e] - m); rs += pv[kb][e]; }
+    lsum += rs;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        uint4 pw;
+        pw.x = pack2bf(pv[kb][ks2 * 8 + 0], pv[kb][ks2 * 8 + 1]);
+        pw.y = pack2bf(pv[kb][ks2 * 8 + 2], pv[kb][ks2 * 8 + 3]);
+        pw.z = pack2bf(pv[kb][ks2 * 8 + 4], pv[kb][ks2 * 8 + 5]);
+        pw.w = pack2bf(pv[kb][ks2 * 8 + 6], pv[kb][ks2 * 8 + 7]);
+        bf16x8 pf = as_bf16x8(pw);
+        const int kd = kb * 16 + ks2 * 8 + 2 * hi;
+        {
+          const uint32_t* r = vt + l31 * V2_VP + kd;
+          uint2 lo = *reinterpret_cast<const uint2*>(r);
+          uint2 h2 = *reinterpret_cast<const uint2*>(r + 4);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(lo.x, lo.y, h2.x, h2.y)), pf, o0, 0, 0, 0);
+        }
+        {
+          const uint32_t* r = vt + (32 + l31) * V2_VP + kd;
+          uint2 lo = *reinterpret_cast<const uint2*>(r);
+          uint2 h2 = *reinterpret_cast<const uint2*>(r + 4);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(make_uint4(lo.x, lo.y, h2.x, h2.y)), pf, o1, 0, 0, 0);
+        }
+      }
+    if (kt + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  float inv = 1.f / ltot;
+  if (qi < p.sq) {
+    lvd_bf16* op = p.o + (qbase + (long)qi * p.q_step) * p.ldo + h * 64 + 4 * hi;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      uint2 w0, w1;
+      w0.x = pack2bf(o0[rq * 4 + 0] * inv, o0[rq * 4 + 1] * inv);
+      w0.y = pack2bf(o0[rq * 4 + 2] * inv, o0[rq * 4 + 3] * inv);
+      w1.x = pack2bf(o1[rq * 4 + 0] * inv, o1[rq * 4 + 1] * inv);
+      w1.y = pack2bf(o1[rq * 4 + 2] * inv, o1[rq * 4 + 3] * inv);
+      stg8(op + 8 * rq, w0);
+      stg8(op + 32 + 8 * rq, w1);
+    }
+    if (p.lse && hi == 0) p.lse[((long)s * p.heads + h) * p.sq + qi] = (m + log2f(ltot)) * 0.6931471805599453f;
+  }
+}
+
 }  // namespace
 
 extern "C" int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream) {
@@ -174,8 +342,16 @@ extern "C" int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream) {
   LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 4 == 0, "attention_fwd: leading dims must be multiples of 8");
   LVD_CHECK(p->heads <= 65535, "attention_fwd: too many heads");
   LVD_CHECK(p->q_ninner > 0 && p->kv_ninner > 0, "attention_fwd: ninner must be > 0");
-  dim3 grid(((p->sq + 31) / 32) * p->samples, p->heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("LVD_ATTN_VARIANT"); force = e ? atoi(e) : 0; }
+  const bool use_v2 = force == 2 || (force == 0 && p->skv2 == 0 && p->sq >= 128 && p->skv >= 128);
+  if (use_v2 && p->skv2 == 0) {
+    dim3 grid(((p->sq + 127) / 128) * p->samples, p->heads);
+    hipLaunchKernelGGL(attn_fwd_v2_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+  } else {
+    dim3 grid(((p->sq + 31) / 32) * p->samples, p->heads);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  }
   LVD_LAUNCH_CHECK();
   return 0;
 }

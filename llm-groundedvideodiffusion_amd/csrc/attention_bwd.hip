@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      float pr = (kidx < p.skv) ? exp2f(st[e] * sc - lse2) : 0.f;
+      float pr = (kidx < p.skv) ? fast_exp2(st[e] * sc - lse2) : 0.f;
       ds[e] = pr * (dpt[e] - delta);
     }
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_par
       int qc = ok ? qidx : p.sq - 1;
       float lse2 = p.lse[sbase + qc] * 1.4426950408889634f;
       float dl = bp.delta[sbase + qc];
-      float pe = ok ? exp2f(sm[e] * sc - lse2) : 0.f;
+      float pe = ok ? fast_exp2(sm[e] * sc - lse2) : 0.f;
       pr[e] = pe;
       ds[e] = pe * (dpm[e] - dl);
     }

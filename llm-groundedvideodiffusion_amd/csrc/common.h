@@ -13,13 +13,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LVD_DEV __device__ __forceinline__
 
 LVD_DEV float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-LVD_DEV uint16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp32 -> bf16 with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, one instruction per pair)
+LVD_DEV uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+LVD_DEV uint32_t pack2bf(float lo, float hi) {
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
-LVD_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// raw v_exp_f32 (2^x): inputs far below the denormal range flush to 0, which is what the softmax wants
+LVD_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LVD_DEV float bflo(uint32_t u) { return __uint_as_float(u << 16); }
 LVD_DEV float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 

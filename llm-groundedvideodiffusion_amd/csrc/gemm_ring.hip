@@ -207,11 +207,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     // tile kt has landed once at most (STAGES-2) younger stages are still outstanding
     wait_vmcnt<(STAGES - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
-    // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1
-    {
-      int nslot = slot == 0 ? STAGES - 1 : slot - 1;
-      stage(kt + STAGES - 1, nslot);
-    }
+    // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1.  With 8 waves (two per SIMD, barrier-locked)
+    // the upper half issues its refill AFTER its MFMA block so that, on every SIMD, one wave's address arithmetic
+    // runs in the shadow of the other wave's MFMAs instead of both doing the same phase at the same time.
+    const int nslot = slot == 0 ? STAGES - 1 : slot - 1;
+    const bool late = (NW == 8) && (wave >= NW / 2);
+    if (!late) stage(kt + STAGES - 1, nslot);
     const uint4* A = lds + slot * TILE;
     const uint4* B = A + BM * RCH;
 #pragma unroll
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = token row
     }
+    if (late) stage(kt + STAGES - 1, nslot);
     slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
   wait_vmcnt<0>();
@@ -334,6 +336,8 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
     case 4: return launch_ring<4, 2, 2, 5, 3>(p, s);
     case 5: return launch_ring<4, 2, 2, 4, 3>(p, s);
     case 8: return launch_ring<4, 2, 2, 4, 2, 64>(p, s);
+    case 9: return launch_ring<4, 2, 2, 4, 4>(p, s);
+    case 10: return launch_ring<4, 2, 2, 5, 4>(p, s);
     default: return 1;
   }
 }

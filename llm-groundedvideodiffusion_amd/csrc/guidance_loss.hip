@@ -78,8 +78,8 @@ __global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params 
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     float mn = fmaxf(m, tmax), rs = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) rs += exp2f(v[e] - mn);
-    lsum = lsum * exp2f(m - mn) + rs;
+    for (int e = 0; e < 16; ++e) rs += fast_exp2(v[e] - mn);
+    lsum = lsum * fast_exp2(m - mn) + rs;
     m = mn;
   }
   float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) s += dot8(qraw[ks], ldg16(kp + ks * 16));
     s += __shfl_xor(s, 32, 64);
-    if (hi == 0 && qi < p.P) p.probs[(row * p.ntok + t) * p.P + qi] = exp2f(s * sc - lse2);
+    if (hi == 0 && qi < p.P) p.probs[(row * p.ntok + t) * p.P + qi] = fast_exp2(s * sc - lse2);
   }
 }
 
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      float pr = kidx < p.ntext ? exp2f(st[e] * sc - lse2) : 0.f;
+      float pr = kidx < p.ntext ? fast_exp2(st[e] * sc - lse2) : 0.f;
       float g = -cq;
 #pragma unroll
       for (int t = 0; t < MAXTOK; ++t) g += (tk[t] == kidx) ? da[t] : 0.f;
