@@ -56,7 +56,8 @@ enum {
   LVD_GEMM_V_RING256N = 9,  /* 256x160 / 256x128 LDS-DMA ring, 4 waves */
   LVD_GEMM_V_REG64 = 10,    /* 128x128x64 register-staged, 2 workgroups/CU */
   LVD_GEMM_V_RING256W = 11, /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
-  LVD_GEMM_V_RING256K64 = 14 /* 256x256x64 LDS-DMA double buffer, 8 waves */
+  LVD_GEMM_V_RING256K64 = 14, /* 256x256x64 LDS-DMA double buffer, 8 waves */
+  LVD_GEMM_V_SPLITK = 20     /* 128x128x32 ring, K split over workgroups + deterministic slab reduction (under-filled grids) */
 };
 
 typedef struct {
@@ -83,6 +84,9 @@ typedef struct {
   float alpha;             /* out = res + alpha * (acc + bias + rowbias) */
   int32_t accumulate;      /* 1: out += (bf16 read-modify-write; used for gradient accumulation) */
   int32_t variant;         /* 0 = library heuristic; >0 pins a tile geometry (LVD_GEMM_V_*), used by the host autotuner */
+  int32_t ksplit;          /* LVD_GEMM_V_SPLITK only: number of K slices (0 = choose from the grid size) */
+  float* ws;               /* split-K workspace, fp32 slabs [ksplit, M, N]; caller-owned */
+  int64_t ws_bytes;
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);

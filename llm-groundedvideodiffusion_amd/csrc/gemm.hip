@@ -317,13 +317,15 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
     //   under-filled grids            -> 128x128x64 register-staged (fewest, longest tiles)
     //   conv / tconv / long-K linear  -> LDS-DMA ring, 3 stages, 3 workgroups per CU
     //   short-K linear                -> 128x128x32 register-staged, 4 workgroups per CU
-    if (tiles < 400) v = 10;
+    if (tiles < 400 && p->ws && p->K >= 1024 && p->act == LVD_ACT_NONE) v = 20;  // split-K (falls back if not splittable)
+    else if (tiles < 400) v = 10;
     else if (p->mode != LVD_A_PLAIN || p->K >= 1024) v = 5;
     else v = 1;
   }
   int rc;
   if (v >= 5 && v <= 8) rc = lvd_gemm_ring_dispatch(p, stream, v - 5);
   else if (v == 14) rc = lvd_gemm_ring_dispatch(p, stream, 8);
+  else if (v == 20) rc = lvd_gemm_ring_dispatch(p, stream, 20);
   else if (v == 15) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 10 : 9);
   else if (v == 11) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
   else if (v == 9) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);

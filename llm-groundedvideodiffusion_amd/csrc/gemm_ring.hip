@@ -33,9 +33,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Source address of one 16-byte chunk of the A operand; written with selects (no divergent branches around the DMA).
 template <int MODE>
-LVD_DEV const lvd_bf16* a_src(const lvd_gemm_params& p, const RowInfo& r, int k0) {
+LVD_DEV const lvd_bf16* a_src(const lvd_gemm_params& p, const RowInfo& r, int k0, int klim) {
   const lvd_bf16* z = reinterpret_cast<const lvd_bf16*>(g_zero_page);
-  bool ok = r.valid && k0 < p.K;
+  bool ok = r.valid && k0 < klim;
   const lvd_bf16* base;
   long off;
   if (MODE == LVD_A_PLAIN) {
@@ -100,7 +100,7 @@ LVD_DEV void wait_vmcnt() {
 }
 
 // WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
-template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK>
+template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
   constexpr int NW = WM * WN;
   constexpr int RCH = RBK / 8;                            // 16-byte chunks per tile row (4: 64 B rows, 8: full 128 B lines)
@@ -129,7 +129,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tiles_n = (p.N + BN - 1) / BN;
+  // split-K: the K slice index is the slowest-varying part of the (XCD-remapped) tile id
+  const int ntile = SPLITK ? nb / p.ksplit : nb;
+  const int slice = SPLITK ? id / ntile : 0;
+  if (SPLITK) id -= slice * ntile;
   const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  int kbeg = 0, klim = p.K;
+  if (SPLITK) {
+    int kchunk = (((p.K + p.ksplit - 1) / p.ksplit + RBK - 1) / RBK) * RBK;
+    kbeg = slice * kchunk;
+    klim = min(p.K, kbeg + kchunk);
+  }
 
   // LDS image is lane-linear per instruction (row = rsub, position = cpos); the bank-conflict swizzle is applied to the
   // SOURCE chunk: RCH=4: pos ^ ((row>>2)&3), RCH=8: pos ^ ((row>>1)&7)  (row parity of 8-row instructions enters via bit 2)
@@ -177,14 +187,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     uint4* B = A + BM * RCH;
 #pragma unroll
     for (int q = 0; q < APW; ++q) {
-      const int k0 = kt * RBK + swz((wave * APW + q) * RPI + rsub, cpos) * 8;
-      const lvd_bf16* src = a_src<MODE>(p, ar[q], k0);
+      const int k0 = kbeg + kt * RBK + swz((wave * APW + q) * RPI + rsub, cpos) * 8;
+      const lvd_bf16* src = a_src<MODE>(p, ar[q], k0, klim);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(A + (wave * APW + q) * RPI * RCH), 16, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < BPW; ++t) {
-      const int k0 = kt * RBK + swz(bins[t] * RPI + rsub, cpos) * 8;
-      const lvd_bf16* src = (wvalid[t] && k0 < p.K) ? p.w + woff[t] + k0 : reinterpret_cast<const lvd_bf16*>(g_zero_page);
+      const int k0 = kbeg + kt * RBK + swz(bins[t] * RPI + rsub, cpos) * 8;
+      const lvd_bf16* src = (wvalid[t] && k0 < klim) ? p.w + woff[t] + k0 : reinterpret_cast<const lvd_bf16*>(g_zero_page);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(B + bins[t] * RPI * RCH), 16, 0, 0);
     }
   };
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (p.K + RBK - 1) / RBK;
+  const int nk = (max(klim - kbeg, 0) + RBK - 1) / RBK;
   // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) stage(s, s);
@@ -245,6 +255,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   // gate / residual / GEGLU are applied on 8-byte row-contiguous vectors with no LDS round trip and no barrier.
   const int mbase = tm * BM + wm * FM * 32;
   const int nbase = tn * BN + wn * FN * 32;
+  if (SPLITK) {  // raw fp32 partial sums into this slice's slab; bias/residual/... happen in splitk_reduce_kernel
+    float* slab = p.ws + (long)slice * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = mbase + i * 32 + l31;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nbase + j * 32 + 8 * q + 4 * hi;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+          *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = v;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = mbase + i * 32 + l31;
@@ -307,6 +337,67 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   }
 }
 
+// deterministic slab reduction + the usual epilogue (bias, temb row-bias, gate, residual, accumulate)
+__global__ void splitk_reduce_kernel(const lvd_gemm_params p) {
+  const long quads = (long)p.M * (p.N >> 2);
+  const long slab = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / (p.N >> 2));
+    const int n = (int)(i - (long)m * (p.N >> 2)) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (long)m * p.N + n);
+    for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + s * slab + (long)m * p.N + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
+    v *= p.alpha;
+    if (p.res) {
+      uint2 r = ldg8(p.res + (long)m * p.ldres + n);
+      v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+    }
+    if (p.out_fp32) {
+      float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    } else {
+      lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+      if (p.accumulate) {
+        uint2 r = ldg8(o);
+        v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+      }
+      uint2 w;
+      w.x = pack2bf(v[0], v[1]);
+      w.y = pack2bf(v[2], v[3]);
+      stg8(o, w);
+    }
+  }
+}
+
+int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
+  lvd_gemm_params p = *pp;
+  const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  int ks = p.ksplit;
+  if (ks <= 0) {
+    ks = (768 + tiles - 1) / tiles;           // aim at ~3 workgroups per CU
+    if (ks > p.K / 256) ks = p.K / 256;       // keep >= 8 K tiles per slice
+    if (ks > 16) ks = 16;
+  }
+  long need = (long)ks * p.M * p.N * 4;
+  if (ks < 2 || p.act != LVD_ACT_NONE || !p.ws || p.ws_bytes < need) return -1;  // caller falls back to the unsplit ring
+  p.ksplit = ks;
+  dim3 grid(tiles * ks), block(256);
+  switch (p.mode) {
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
+    default: return 1;
+  }
+  long quads = (long)p.M * (p.N / 4);
+  int rb = (int)((quads + 255) / 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, p);
+  return 0;
+}
+
 template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32>
 int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
@@ -328,6 +419,11 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
 //           4 = 256x320 8 waves (3 stages), 5 = 256x256 8 waves (3 stages), 8 = 256x256x64 8 waves (2 stages)
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
   hipStream_t s = (hipStream_t)stream;
+  if (geometry == 20) {
+    int rc = launch_splitk(p, s);
+    if (rc >= 0) return rc;
+    geometry = 0;  // not splittable (no workspace / GEGLU / too little K): plain 128x128 ring
+  }
   switch (geometry) {
     case 0: return launch_ring<2, 2, 2, 2, 3>(p, s);
     case 1: return launch_ring<2, 2, 2, 2, 4>(p, s);

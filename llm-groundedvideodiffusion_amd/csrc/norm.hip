@@ -50,16 +50,23 @@ __global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
   }
 }
 
-// grid samples*groups, block 64
-__global__ void gn_finalize_kernel(const lvd_gn_stats_params p) {
-  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
+// one wave per (sample, group), 4 per block; lanes own channels of the group and walk the chunks with independent
+// (unrolled) loads so the kernel is one memory round trip deep instead of chunks*cpg/64 dependent ones
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const lvd_gn_stats_params p, int total) {
+  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sg >= total) return;
+  const int s = sg / p.groups, g = sg % p.groups;
   const int cpg = p.c / p.groups;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   float a = 0.f, b = 0.f;
-  for (int i = lane; i < p.chunks * cpg; i += 64) {
-    int ch = i / cpg, cc = i % cpg;
-    const float* q = p.partial + (((long)s * p.chunks + ch) * p.c + g * cpg + cc) * 2;
-    a += q[0]; b += q[1];
+  for (int cc = lane; cc < cpg; cc += 64) {
+    const float* q = p.partial + ((long)s * p.chunks * p.c + g * cpg + cc) * 2;
+    const long stride = (long)p.c * 2;
+#pragma unroll 8
+    for (int ch = 0; ch < p.chunks; ++ch) {
+      float2 v = *reinterpret_cast<const float2*>(q + ch * stride);
+      a += v.x; b += v.y;
+    }
   }
   a = wave_sum(a); b = wave_sum(b);
   float cnt = (float)cpg * (float)p.rows_per_sample;
@@ -158,15 +165,21 @@ __global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, i
   }
 }
 
-__global__ void gn_bwd_finalize_kernel(const lvd_gn_bwd_stats_params p) {
-  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const lvd_gn_bwd_stats_params p, int total) {
+  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sg >= total) return;
+  const int s = sg / p.groups, g = sg % p.groups;
   const int cpg = p.c / p.groups;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   float a = 0.f, b = 0.f;
-  for (int i = lane; i < p.chunks * cpg; i += 64) {
-    int ch = i / cpg, cc = i % cpg;
-    const float* q = p.partial + (((long)s * p.chunks + ch) * p.c + g * cpg + cc) * 2;
-    a += q[0]; b += q[1];
+  for (int cc = lane; cc < cpg; cc += 64) {
+    const float* q = p.partial + ((long)s * p.chunks * p.c + g * cpg + cc) * 2;
+    const long stride = (long)p.c * 2;
+#pragma unroll 8
+    for (int ch = 0; ch < p.chunks; ++ch) {
+      float2 v = *reinterpret_cast<const float2*>(q + ch * stride);
+      a += v.x; b += v.y;
+    }
   }
   a = wave_sum(a); b = wave_sum(b);
   float cnt = (float)cpg * (float)p.rows_per_sample;
@@ -328,7 +341,7 @@ extern "C" int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 8 * sizeof(float), s, *p, VC, RL);
   LVD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(samples * p->groups), dim3(64), 0, s, *p);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((samples * p->groups + 3) / 4), dim3(256), 0, s, *p, samples * p->groups);
   LVD_LAUNCH_CHECK();
   return 0;
 }
@@ -353,7 +366,7 @@ extern "C" int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 8 * sizeof(float), s, *p, VC, RL);
   LVD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(samples * p->groups), dim3(64), 0, s, *p);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((samples * p->groups + 3) / 4), dim3(256), 0, s, *p, samples * p->groups);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -57,6 +57,18 @@ class ConvGeom:
 # 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
 GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14)
+SPLITK_VARIANT = 20
+_splitk_ws = {}
+
+
+def _splitk_workspace(dev, nbytes):
+    """One grow-only fp32 workspace per device for the split-K slabs (stream-ordered reuse is safe: every user is a
+    GEMM+reduce pair on the same stream)."""
+    ws = _splitk_ws.get(dev)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((max(nbytes, 64 << 20) + 3) // 4, dtype=torch.float32, device=dev)
+        _splitk_ws[dev] = ws
+    return ws
 _gemm_choice = {}
 _autotune = {"enabled": True, "min_flops": 2e9}
 
@@ -78,7 +90,8 @@ def _tune_gemm(p, key, out):
     saved_out, saved_acc = p.out, p.accumulate
     p.out, p.accumulate = scratch.data_ptr(), 0
     best, best_t = 0, float("inf")
-    for v in GEMM_CANDIDATES:
+    cands = GEMM_CANDIDATES + ((SPLITK_VARIANT,) if p.ws else ())
+    for v in cands:
         p.variant = v
         _launch_gemm(p)  # warm-up (also instruction-cache / L2)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -127,6 +140,10 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     p.ldres = _ld(res) if res is not None else 0
     p.ldc = _ld(out)
     p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
+    tiles = ((m + 127) // 128) * ((N + 127) // 128)
+    if act == ACT_NONE and tiles < 512 and K >= 1024:  # under-filled grid: offer the split-K path a workspace
+        ws = _splitk_workspace(a1.device, 16 * m * N * 4)
+        p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if variant == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"] and not torch.cuda.is_current_stream_capturing():
         key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample) if conv is not None else None, int(out_fp32))
         variant = _gemm_choice.get(key) or _tune_gemm(p, key, out)
