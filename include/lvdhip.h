@@ -57,6 +57,7 @@ enum {
   LVD_GEMM_V_REG64 = 10,    /* 128x128x64 register-staged, 2 workgroups/CU */
   LVD_GEMM_V_RING256W = 11, /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
   LVD_GEMM_V_RING256K64 = 14, /* 256x256x64 LDS-DMA double buffer, 8 waves */
+  LVD_GEMM_V_RING128x320 = 17, /* 128x320x32 LDS-DMA double buffer (N = 320·k exactly), 2 workgroups/CU */
   LVD_GEMM_V_SPLITK = 20     /* 128x128x32 ring, K split over workgroups + deterministic slab reduction (under-filled grids) */
 };
 

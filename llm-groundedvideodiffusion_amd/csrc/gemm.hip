@@ -326,7 +326,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   if (v >= 5 && v <= 8) rc = lvd_gemm_ring_dispatch(p, stream, v - 5);
   else if (v == 14) rc = lvd_gemm_ring_dispatch(p, stream, 8);
   else if (v == 20) rc = lvd_gemm_ring_dispatch(p, stream, 20);
-  else if (v == 15) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 10 : 9);
+  else if (v == 17) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 12 : 0);
   else if (v == 11) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
   else if (v == 9) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
   else if (v == 1) rc = launch_gemm<32, 3>(p, grid, s);

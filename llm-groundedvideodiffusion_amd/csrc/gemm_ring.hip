@@ -432,8 +432,7 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
     case 4: return launch_ring<4, 2, 2, 5, 3>(p, s);
     case 5: return launch_ring<4, 2, 2, 4, 3>(p, s);
     case 8: return launch_ring<4, 2, 2, 4, 2, 64>(p, s);
-    case 9: return launch_ring<4, 2, 2, 4, 4>(p, s);
-    case 10: return launch_ring<4, 2, 2, 5, 4>(p, s);
+    case 12: return launch_ring<2, 2, 2, 5, 2>(p, s);
     default: return 1;
   }
 }

@@ -56,7 +56,7 @@ class ConvGeom:
 # (M, N, K, loader): short-K linears favour many small workgroups, long-K convs the LDS-DMA ring, and the
 # 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
-GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14)
+GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17)
 SPLITK_VARIANT = 20
 _splitk_ws = {}
 

@@ -335,7 +335,7 @@ def test_elementwise():
     assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14])
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
     epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
