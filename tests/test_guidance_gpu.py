@@ -27,12 +27,12 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("mode", ["spatial", "temporal", "cross"])
+@pytest.mark.parametrize("mode", ["spatial", "spatial_long", "temporal", "cross"])
 def test_attention_backward(mode):
     H = 2
     C = H * 64
-    if mode == "spatial":
-        S, sq, skv = 3, 70, 70
+    if mode in ("spatial", "spatial_long"):
+        S, sq, skv = (3, 70, 70) if mode == "spatial" else (2, 200, 200)  # >= 128 keys/queries: LDS-shared v2 kernels
         rows = S * sq
         qm = km = ops.RowMap(1, sq, 0, 1)
         perm = lambda t, L: t.reshape(S, L, H, 64).permute(0, 2, 1, 3)
