@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Batch driver with the reference's command line (generate.py:13-108) on the MI355X sampler.
+
+    python generate.py --model gpt-4 --run-model lvd_zeroscope --prompt-type demo --template_version v0.1 \
+        --num_frames 24 --cache-dir /path/to/cache [--repeats N --seed_offset S --force_run_ind K ...]
+
+Kept from the reference: flag names, run-model dispatch (:111-165), cache lookup per prompt (:278), run-dir / resume
+logic (:225-239,288-299), the seed rule seed = prompt_index + repeat*6789 + seed_offset (:325-335), prompt sharding by
+--skip_first_prompts/--num_prompts (:255-262) and error containment (:340-353).  Added: under torchrun every rank takes
+the prompt indices i % WORLD_SIZE == RANK (one process per GPU, no communication while sampling), and
+--synthetic-weights for runs without a checkpoint (there is no network for hub downloads)."""
+import argparse
+import importlib
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RUN_MODELS = ["lvd", "lvd_zeroscope", "lvd_modelscope256", "lvd-gligen_modelscope256", "lvd-gligen_zeroscope", "lvd-plus_modelscope256",
+              "lvd-plus_zeroscope", "lvd_modelscope512", "modelscope", "modelscope_256", "zeroscope"]
+MODEL_NAMES = {"gpt-4": "gpt-4-1106-preview", "gpt-4-1106-preview": "gpt-4-1106-preview", "gpt-3.5": "gpt-3.5-turbo", "gpt-3.5-turbo": "gpt-3.5-turbo"}
+PROMPTS_DEMO = ["A bear walks from the left to the right"]  # prompt.py:72-74
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--save-suffix", default=None, type=str)
+    p.add_argument("--model", choices=sorted(MODEL_NAMES), required=True, help="LLM model to load the cache from")
+    p.add_argument("--repeats", default=1, type=int)
+    p.add_argument("--regenerate", default=1, type=int)
+    p.add_argument("--force_run_ind", default=None, type=int)
+    p.add_argument("--skip_first_prompts", default=0, type=int)
+    p.add_argument("--seed_offset", default=0, type=int)
+    p.add_argument("--num_prompts", default=None, type=int)
+    p.add_argument("--run-model", default="lvd", choices=RUN_MODELS)
+    p.add_argument("--no-continue-on-error", action="store_true")
+    p.add_argument("--prompt-type", type=str, default="demo")
+    p.add_argument("--template_version", choices=["v0.1"], required=True)
+    p.add_argument("--dry-run", action="store_true", help="skip the generation")
+    for a in ["fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "loss_threshold", "loss_scale", "boxdiff_loss_scale", "com_loss_scale",
+              "gligen_scheduled_sampling_beta"]:
+        p.add_argument("--" + a, default=None, type=float)
+    for a in ["num_inference_steps", "max_iter", "max_index_step", "num_frames", "use_ratio_based_loss", "boxdiff_normed"]:
+        p.add_argument("--" + a, default=None, type=int)
+    # additions
+    p.add_argument("--cache-dir", default="cache", help="directory holding cache_{prompt_type}_{template}_{model}.json")
+    p.add_argument("--prompts-file", default=None, help="one prompt per line (prompt types other than demo)")
+    p.add_argument("--synthetic-weights", action="store_true", help="random-init weights of the real topology (no checkpoint on disk)")
+    p.add_argument("--checkpoint", default=None, help="torch-saved reference state_dict of the UNet")
+    p.add_argument("--img-root", default="img_generations")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    run_model = args.run_model
+    baseline = run_model in ("modelscope", "zeroscope", "modelscope_256")
+    option = run_model.split("_")[1] if "_" in run_model else ""
+    run = None
+    if not args.dry_run:
+        import torch
+        import lvd_amd  # noqa: F401
+        from lvd_amd.generation import _common
+        if args.synthetic_weights:
+            _common.configure(state_dict="synthetic")
+        elif args.checkpoint:
+            _common.configure(state_dict=torch.load(args.checkpoint, map_location="cpu"))
+        _common.configure(device=f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        modname = {"lvd-plus": "lvd_plus", "lvd-gligen": "lvd_gligen", "lvd": "lvd", "modelscope": "modelscope_dpm", "zeroscope": "zeroscope_dpm"}[run_model.split("_")[0]]
+        generation = importlib.import_module(f"lvd_amd.generation.{modname}")
+        H, W = generation.init(option) if baseline else generation.init(base_model=option if option else "modelscope512")
+        if "zeroscope" in run_model and ((args.num_frames is not None and args.num_frames < 24) or (not baseline and args.num_frames is None)):
+            raise ValueError("Running zeroscope with fewer than 24 frames. This may lead to suboptimal results.")
+        assert generation.version == run_model.split("_")[0], f"{generation.version} != {run_model.split('_')[0]}"
+        run = generation.run
+
+    from lvd_amd import dsl
+    model = MODEL_NAMES[args.model]
+    cache = None
+    if not baseline:
+        cache = dsl.LayoutCache(os.path.join(args.cache_dir, f"cache_{args.prompt_type}_{args.template_version}_{model}.json"))
+    if args.prompt_type == "demo":
+        prompts = PROMPTS_DEMO
+    elif args.prompts_file:
+        prompts = [l.strip() for l in open(args.prompts_file) if l.strip()]
+    else:
+        prompts = list(cache.data.keys()) if cache else []
+    run_kwargs = {k: getattr(args, k) for k in ["fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "loss_threshold", "loss_scale", "boxdiff_loss_scale",
+                                                 "com_loss_scale", "gligen_scheduled_sampling_beta", "num_inference_steps", "max_iter", "max_index_step",
+                                                 "num_frames", "use_ratio_based_loss", "boxdiff_normed"] if getattr(args, k) is not None}
+    base_save = f"{args.img_root}/imgs_{args.prompt_type}_template{args.template_version}_{run_model}" + (f"_{args.save_suffix}" if args.save_suffix else "")
+    if args.force_run_ind is not None:
+        run_ind = args.force_run_ind
+    else:
+        run_ind = 0
+        while os.path.exists(f"{base_save}/run{run_ind}"):
+            run_ind += 1
+    save_dir = f"{base_save}/run{run_ind}"
+    print(f"Save dir: {save_dir}  (rank {rank}/{world})")
+
+    ind, generated = 0, 0
+    for regenerate_ind in range(args.regenerate):
+        if cache:
+            cache.reset_access()
+        for prompt_ind, prompt in enumerate(prompts):
+            skip = prompt_ind < args.skip_first_prompts or (args.num_prompts is not None and prompt_ind >= args.skip_first_prompts + args.num_prompts)
+            prompt = prompt.strip().rstrip(".")
+            resp = None if baseline else cache.get(prompt)  # every rank walks the cache identically (sequential semantics)
+            if skip or ind % world != rank:
+                ind += 1
+                continue
+            if not baseline and resp is None:
+                print(f"Cache miss, skipping prompt: {prompt}")
+                ind += 1
+                continue
+            img_dir = f"{save_dir}/{ind}"
+            done = os.path.exists(img_dir) and len([f for f in os.listdir(img_dir) if f.endswith("joblib")]) >= args.repeats
+            if done:
+                print(f"Image exists at {img_dir}, skipping")
+                ind += 1
+                continue
+            os.makedirs(img_dir, exist_ok=True)
+            try:
+                layout = {"Prompt": prompt, "Background keyword": "", **{f"Frame {k + 1}": [] for k in range(6)}} if baseline else dsl.parse_layout_response(prompt, resp)
+                print("parsed_layout:", layout)
+                if not args.dry_run:
+                    from lvd_amd.generation import _common
+                    _common.configure(img_dir=img_dir)
+                    for repeat_ind in range(args.repeats):
+                        run(layout, seed=ind + repeat_ind * 6789 + args.seed_offset, repeat_ind=repeat_ind, **run_kwargs)
+                        generated += 1
+            except KeyboardInterrupt:
+                raise SystemExit(1)
+            except RuntimeError:
+                print("***RuntimeError: might run out of memory, skipping the current one***")
+                print(traceback.format_exc())
+                time.sleep(1)
+            except Exception as e:  # noqa: BLE001
+                print(f"***Error: {e}***")
+                print(traceback.format_exc())
+                if args.no_continue_on_error:
+                    raise
+            ind += 1
+    print(f"rank {rank}: generated {generated} video(s)")
+    return generated
+
+
+if __name__ == "__main__":
+    main()

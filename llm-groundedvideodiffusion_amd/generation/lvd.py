@@ -1,0 +1,14 @@
+"""Run-model `lvd` (reference: generation/lvd.py) on the HIP denoiser; the shared runner is _common.Method."""
+from ._common import Method, configure  # noqa: F401
+
+_m = Method("lvd", use_guidance=True, use_gligen=False)
+version = _m.version
+
+
+def init(base_model):
+    """base_model in {"zeroscope", "modelscope256", "modelscope512"} -> (H, W)."""
+    return _m.init(base_model)
+
+
+def run(parsed_layout, seed, **kwargs):
+    return _m.run(parsed_layout, seed, **kwargs)

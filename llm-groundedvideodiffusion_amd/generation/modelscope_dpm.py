@@ -1,0 +1,13 @@
+"""Baseline run-model `modelscope` (reference: generation/modelscope_dpm.py) on the HIP denoiser."""
+from ._common import Method, configure  # noqa: F401
+
+_m = Method("modelscope", use_guidance=False, use_gligen=False)
+version = _m.version
+
+
+def init(option=""):
+    return _m.init("modelscope256" if option == "256" else "modelscope512")
+
+
+def run(parsed_layout, seed, **kwargs):
+    return _m.run(parsed_layout, seed, **kwargs)

@@ -30,3 +30,58 @@ class FakeTokenizer:
 
     def _convert_id_to_token(self, i):
         return self.inv[int(i)]
+
+
+class _Batch(dict):
+    def __getattr__(self, k):
+        return self[k]
+
+    def to(self, device):
+        return _Batch({k: v.to(device) for k, v in self.items()})
+
+
+class FakeClipTokenizer(FakeTokenizer):
+    """Adds the padding / torch-tensor call styles the pipeline uses (max_length padding, `padding=True`, `.to(device)`)."""
+
+    def __call__(self, texts, padding="do_not_pad", max_length=77, return_tensors="np", truncation=False, **kw):
+        import torch
+        if isinstance(texts, str):
+            texts = [texts]
+        if return_tensors == "np":
+            return super().__call__(texts, padding=padding, max_length=max_length, return_tensors="np")
+        rows = [list(super(FakeClipTokenizer, self).__call__([t], max_length=max_length)["input_ids"][0]) for t in texts]
+        width = max_length if padding == "max_length" else max(len(r) for r in rows)
+        rows = [r + [1] * (width - len(r)) for r in rows]
+        return _Batch(input_ids=torch.tensor(rows, dtype=torch.long))
+
+
+class FakeTextEncoder:
+    """Deterministic stand-in for CLIPTextModel: hashed-id embeddings, `[0]` = hidden states, `.pooler_output` = mean."""
+    dtype = None
+
+    def __init__(self, dim):
+        import torch
+        self.dim = dim
+        self.dtype = torch.float32
+
+    def __call__(self, input_ids=None, **kw):
+        import torch
+        ids = input_ids
+        g = torch.Generator().manual_seed(1234)
+        table = torch.randn(4096, self.dim, generator=g)
+        h = table[(ids.cpu() * 2654435761 % 4096).long()] + 0.1 * torch.arange(ids.shape[1])[None, :, None] / ids.shape[1]
+        h = h.to(ids.device)
+
+        class Out(tuple):
+            pass
+        out = Out((h,))
+        out.pooler_output = h.mean(1)
+        return out
+
+
+def fake_vae_decode(latents):
+    """Test stand-in for AutoencoderKL.decode + tensor2vid: (1,4,F,h,w) latents -> (1,F,8h,8w,3) floats in [0,1]."""
+    import torch
+    x = latents[:, :3].permute(0, 2, 3, 4, 1)  # (1,F,h,w,3)
+    x = torch.sigmoid(x).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    return x.float().cpu().numpy()

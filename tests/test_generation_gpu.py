@@ -1,0 +1,77 @@
+"""GPU tests of the run-model protocol and the batch driver (generate.py) with injected stand-ins for the 'next' rows
+(CLIP tokenizer/text encoder, VAE): files, shapes, resume/skip behaviour, seed rule, GLIGEN variants."""
+import json
+import os
+
+import joblib
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import lvd_amd  # noqa: E402
+from lvd_amd import dsl  # noqa: E402
+from lvd_amd.generation import _common, lvd, lvd_gligen, lvd_plus, zeroscope_dpm  # noqa: E402
+from lvd_amd.weights import UNetConfig, synthetic_state_dict  # noqa: E402
+from oracle.fake_tokenizer import FakeClipTokenizer, FakeTextEncoder, fake_vae_decode  # noqa: E402
+
+CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dsl.json")))
+SMALL = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=2, cross_attention_dim=64, attention_head_dim=64)
+
+
+def _configure(tmp_path, gated):
+    cfg = UNetConfig(attention_type="gated" if gated else "default", **SMALL)
+    _common.configure(state_dict=synthetic_state_dict(cfg, seed=0), unet_config=dict(SMALL), tokenizer=FakeClipTokenizer(),
+                      text_encoder=FakeTextEncoder(64), vae=fake_vae_decode, device="cuda", img_dir=str(tmp_path))
+
+
+def test_lvd_run_writes_reference_file_contract(tmp_path):
+    _configure(tmp_path, gated=False)
+    assert lvd.version == "lvd" and lvd.init("zeroscope") == (320, 576)
+    demo = [c for c in CASES if c["cache"].startswith("cache_demo")][0]
+    layout = dsl.parse_layout_response(demo["prompt"], demo["response"])
+    frames = lvd.run(layout, seed=7, num_inference_steps=4, num_frames=24, repeat_ind=0, loss_scale=2.5, loss_threshold=0.5, max_iter=1,
+                     max_index_step=2, fg_top_p=0.25, bg_top_p=0.25, bg_weight=2.0)
+    assert frames.dtype == np.uint8 and frames.shape == (24, 320, 576, 3)
+    back = joblib.load(tmp_path / "video_0.joblib")
+    assert np.array_equal(back, frames) and (tmp_path / "video_0.gif").exists()
+    assert lvd.run(layout, seed=7, num_inference_steps=4, num_frames=24, repeat_ind=0) is None  # existing gif -> skipped
+    again = lvd.run(layout, seed=7, num_inference_steps=4, num_frames=24, repeat_ind=1, loss_scale=2.5, loss_threshold=0.5, max_iter=1,
+                    max_index_step=2, fg_top_p=0.25, bg_top_p=0.25, bg_weight=2.0)
+    other = lvd.run(layout, seed=8, num_inference_steps=4, num_frames=24, repeat_ind=2, max_index_step=0)
+    assert np.array_equal(again, frames) and not np.array_equal(other, frames)  # output is a function of the seed
+
+
+@pytest.mark.parametrize("mod,name", [(lvd_gligen, "lvd-gligen"), (lvd_plus, "lvd-plus"), (zeroscope_dpm, "zeroscope")])
+def test_other_run_models(tmp_path, mod, name):
+    _configure(tmp_path, gated=name != "zeroscope")
+    assert mod.version == name
+    hw = mod.init("modelscope256") if name != "zeroscope" else mod.init("")
+    case = [c for c in CASES if any(all(v == 0 for v in fb) for b in c["boxes"] for fb in b)][0]  # an object disappears
+    layout = dsl.parse_layout_response(case["prompt"], case["response"])
+    kw = dict(gligen_scheduled_sampling_beta=0.5) if name != "zeroscope" else {}
+    frames = mod.run(layout, seed=3, num_inference_steps=4, num_frames=16, repeat_ind=0, max_index_step=1, max_iter=1, **kw)
+    assert frames.shape == (16, hw[0], hw[1], 3) and frames.dtype == np.uint8
+
+
+def test_generate_cli_resume_and_seed_rule(tmp_path, monkeypatch):
+    import generate
+    demo = [c for c in CASES if c["cache"].startswith("cache_demo")][0]
+    cache_dir = tmp_path / "cache"
+    cache_dir.mkdir()
+    (cache_dir / "cache_demo_v0.1_gpt-4-1106-preview.json").write_text(json.dumps({demo["prompt"]: [demo["response"]]}))
+    _configure(tmp_path, gated=False)
+    seeds = []
+    orig = lvd._m.run
+    monkeypatch.setattr(lvd._m, "run", lambda layout, seed, **kw: (seeds.append(seed), orig(layout, seed, **kw))[1])
+    argv = ["--model", "gpt-4", "--run-model", "lvd_zeroscope", "--prompt-type", "demo", "--template_version", "v0.1", "--num_frames", "24",
+            "--num_inference_steps", "3", "--max_index_step", "1", "--max_iter", "1", "--repeats", "2", "--seed_offset", "5", "--force_run_ind", "0",
+            "--cache-dir", str(cache_dir), "--img-root", str(tmp_path / "out")]
+    assert generate.main(argv) == 2
+    assert seeds == [0 + 5, 6789 + 5]
+    run_dir = tmp_path / "out" / "imgs_demo_templatev0.1_lvd_zeroscope" / "run0" / "0"
+    assert sorted(f for f in os.listdir(run_dir) if f.endswith(".joblib")) == ["video_0.joblib", "video_1.joblib"]
+    assert generate.main(argv) == 0  # resumed: both repeats exist
+    with pytest.raises(ValueError):
+        generate.main([a if a != "24" else "16" for a in argv])  # zeroscope with < 24 frames is refused like in the reference
