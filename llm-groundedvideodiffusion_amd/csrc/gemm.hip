@@ -289,6 +289,7 @@ int launch_gemm(const lvd_gemm_params* p, dim3 grid, hipStream_t s) {
 }  // namespace
 
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_ring.hip
+int lvd_gemm_pers_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_pers.hip
 
 extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   LVD_CHECK(p && p->a1 && p->w && p->out, "gemm: null pointer");
@@ -329,6 +330,10 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   else if (v == 17) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 12 : 0);
   else if (v == 11) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
   else if (v == 9) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
+  else if (v == 21) rc = lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
+  else if (v == 22) rc = lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 12 : 13);
+  else if (v == 23) rc = lvd_gemm_pers_dispatch(p, stream, 0);
+  else if (v == 24) rc = lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
   else if (v == 1) rc = launch_gemm<32, 3>(p, grid, s);
   else if (v == 2) rc = launch_gemm<32, 4>(p, grid, s);
   else rc = launch_gemm<64, 2>(p, grid, s);

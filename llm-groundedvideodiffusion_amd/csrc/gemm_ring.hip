@@ -17,87 +17,9 @@
 #include <cstdlib>
 #include "common.h"
 
+#include "gemm_tile.h"
+
 namespace {
-
-
-__device__ uint4 g_zero_page[4];
-
-struct RowInfo {
-  long off1, off2;
-  int oy, ox;
-  bool valid;
-};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Source address of one 16-byte chunk of the A operand; written with selects (no divergent branches around the DMA).
-template <int MODE>
-LVD_DEV const lvd_bf16* a_src(const lvd_gemm_params& p, const RowInfo& r, int k0, int klim) {
-  const lvd_bf16* z = reinterpret_cast<const lvd_bf16*>(g_zero_page);
-  bool ok = r.valid && k0 < klim;
-  const lvd_bf16* base;
-  long off;
-  if (MODE == LVD_A_PLAIN) {
-    bool s2 = k0 >= p.c1;
-    base = s2 ? p.a2 : p.a1;
-    off = s2 ? r.off2 + (k0 - p.c1) : r.off1 + k0;
-  } else if (MODE == LVD_A_CONV3X3) {
-    int tap = k0 / p.cin;
-    int c = k0 - tap * p.cin;
-    int ky = tap / 3, kx = tap - 3 * ky;
-    int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
-    ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
-    int ws = p.win >> p.upsample;
-    iy >>= p.upsample; ix >>= p.upsample;
-    long row = r.off1 + (long)iy * ws + ix;
-    bool s2 = c >= p.c1;
-    base = s2 ? p.a2 : p.a1;
-    off = s2 ? row * p.lda2 + (c - p.c1) : row * p.lda1 + c;
-  } else if (MODE == LVD_A_CONV3X3_T2) {
-    int tap = k0 / p.cin;
-    int c = k0 - tap * p.cin;
-    int ky = tap / 3, kx = tap - 3 * ky;
-    int ty = r.oy + 1 - ky, tx = r.ox + 1 - kx;
-    ok = ok && ty >= 0 && tx >= 0 && !((ty | tx) & 1);
-    ty >>= 1; tx >>= 1;
-    ok = ok && ty < p.hin && tx < p.win;
-    base = p.a1;
-    off = (r.off1 + (long)ty * p.win + tx) * p.lda1 + c;
-  } else {
-    int tap = k0 / p.cin;
-    int c = k0 - tap * p.cin;
-    int ff = r.oy + tap - 1;
-    ok = ok && ff >= 0 && ff < p.frames;
-    long row = r.off1 + (long)(tap - 1) * p.hw;
-    bool s2 = c >= p.c1;
-    base = s2 ? p.a2 : p.a1;
-    off = s2 ? row * p.lda2 + (c - p.c1) : row * p.lda1 + c;
-  }
-  return ok ? base + off : z;
-}
-
-template <int N>
-LVD_DEV void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  else if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 
 // WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
 template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false>
@@ -148,27 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 
   RowInfo ar[APW];
 #pragma unroll
-  for (int q = 0; q < APW; ++q) {
-    int m = tm * BM + (wave * APW + q) * RPI + rsub;
-    ar[q].valid = m < p.M;
-    ar[q].off1 = 0; ar[q].off2 = 0; ar[q].oy = 0; ar[q].ox = 0;
-    if (MODE == LVD_A_PLAIN) {
-      ar[q].off1 = (long)m * p.lda1;
-      ar[q].off2 = (long)m * p.lda2;
-    } else if (MODE == LVD_A_CONV3X3 || MODE == LVD_A_CONV3X3_T2) {
-      int plane = p.hout * p.wout;
-      int nimg = m / plane;
-      int rem = m - nimg * plane;
-      ar[q].oy = rem / p.wout;
-      ar[q].ox = rem - ar[q].oy * p.wout;
-      int hs = p.hin, ws = p.win;
-      if (MODE == LVD_A_CONV3X3 && p.upsample) { hs >>= 1; ws >>= 1; }
-      ar[q].off1 = (long)nimg * hs * ws;
-    } else {
-      ar[q].off1 = m;
-      ar[q].oy = (m / p.hw) % p.frames;
-    }
-  }
+  for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, tm * BM + (wave * APW + q) * RPI + rsub, true);
   long woff[BPW];
   bool wvalid[BPW];
   int bins[BPW];
@@ -182,21 +84,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     woff[t] = (long)n * p.K;
   }
 
-  auto stage = [&](int kt, int slot) {
+  // one wave-wide LDS-DMA instruction of tile kt (idx < APW: A rows, else B rows)
+  auto stage_one = [&](int kt, int slot, int idx) {
     uint4* A = lds + slot * TILE;
     uint4* B = A + BM * RCH;
-#pragma unroll
-    for (int q = 0; q < APW; ++q) {
+    if (idx < APW) {
+      const int q = idx;
       const int k0 = kbeg + kt * RBK + swz((wave * APW + q) * RPI + rsub, cpos) * 8;
       const lvd_bf16* src = a_src<MODE>(p, ar[q], k0, klim);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(A + (wave * APW + q) * RPI * RCH), 16, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < BPW; ++t) {
+    } else {
+      const int t = idx - APW;
       const int k0 = kbeg + kt * RBK + swz(bins[t] * RPI + rsub, cpos) * 8;
       const lvd_bf16* src = (wvalid[t] && k0 < klim) ? p.w + woff[t] + k0 : reinterpret_cast<const lvd_bf16*>(g_zero_page);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(B + bins[t] * RPI * RCH), 16, 0, 0);
     }
+  };
+  auto stage = [&](int kt, int slot) {
+#pragma unroll
+    for (int idx = 0; idx < LPS; ++idx) stage_one(kt, slot, idx);
   };
 
   f32x16 acc[FM][FN];
@@ -217,12 +123,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     // tile kt has landed once at most (STAGES-2) younger stages are still outstanding
     wait_vmcnt<(STAGES - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
-    // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1.  With 8 waves (two per SIMD, barrier-locked)
-    // the upper half issues its refill AFTER its MFMA block so that, on every SIMD, one wave's address arithmetic
-    // runs in the shadow of the other wave's MFMAs instead of both doing the same phase at the same time.
+    // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1, one DMA instruction every IVL MFMAs: the
+    // address arithmetic hides in the MFMA shadow and the L2 sees a steady request stream instead of a burst per barrier.
     const int nslot = slot == 0 ? STAGES - 1 : slot - 1;
-    const bool late = (NW == 8) && (wave >= NW / 2);
-    if (!late) stage(kt + STAGES - 1, nslot);
+    constexpr int NMF = (RBK / 16) * FM * FN;            // MFMAs per wave per K tile
+    constexpr int IVL = NMF / LPS > 0 ? NMF / LPS : 1;   // one DMA instruction every IVL MFMAs: a steady request stream
     const uint4* A = lds + slot * TILE;
     const uint4* B = A + BM * RCH;
 #pragma unroll
@@ -242,17 +147,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) {
+          const int cnt = (ks * FM + i) * FN + j;
+          if (cnt % IVL == 0 && cnt / IVL < LPS) stage_one(kt + STAGES - 1, nslot, cnt / IVL);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = token row
+        }
     }
-    if (late) stage(kt + STAGES - 1, nslot);
+    if (LPS > NMF) {
+#pragma unroll
+      for (int idx = NMF; idx < LPS; ++idx) stage_one(kt + STAGES - 1, nslot, idx);
+    }
     slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
   wait_vmcnt<0>();
 
-  // ---- epilogue straight from registers.  The MFMAs were issued as D = W_frag · X_frag^T, so lane (l31) owns token
-  // row m and every 4 consecutive accumulator registers are 4 consecutive output channels: bias / temb row-bias /
-  // gate / residual / GEGLU are applied on 8-byte row-contiguous vectors with no LDS round trip and no barrier.
   const int mbase = tm * BM + wm * FM * 32;
   const int nbase = tn * BN + wn * FN * 32;
   if (SPLITK) {  // raw fp32 partial sums into this slice's slab; bias/residual/... happen in splitk_reduce_kernel
@@ -275,66 +183,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = mbase + i * 32 + l31;
-    if (m >= p.M) continue;
-    if (p.act == LVD_ACT_GEGLU) {
-      lvd_bf16* orow = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc;
-#pragma unroll
-      for (int b = 0; b < FN / 2; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nbase + b * 64 + 8 * q + 4 * hi;  // hidden column in the interleaved W'; gate = n + 32
-          if (n + 32 >= p.N) continue;
-          f32x4 h, g;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
-          if (p.bias) {
-            h += *reinterpret_cast<const f32x4*>(p.bias + n);
-            g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-          }
-          uint2 o;
-          o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-          o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
-          stg8(orow + (nbase >> 1) + b * 32 + 8 * q + 4 * hi, o);
-        }
-      continue;
-    }
-    const float* rb = p.rowbias ? p.rowbias + (long)(m / p.rows_per_sample) * p.N : nullptr;
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = nbase + j * 32 + 8 * q + 4 * hi;
-        if (n >= p.N) continue;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
-        v *= p.alpha;
-        if (p.res) {
-          uint2 r = ldg8(p.res + (long)m * p.ldres + n);
-          v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
-        }
-        if (p.out_fp32) {
-          float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
-          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
-          *reinterpret_cast<f32x4*>(o) = v;
-        } else {
-          lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
-          if (p.accumulate) {
-            uint2 r = ldg8(o);
-            v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
-          }
-          uint2 w;
-          w.x = pack2bf(v[0], v[1]);
-          w.y = pack2bf(v[2], v[3]);
-          stg8(o, w);
-        }
-      }
-  }
+  // the ring is idle now: every wave transposes its accumulators through its own share of it
+  constexpr int WAVE_DW = STAGES * TILE * 4 / NW;
+  static_assert(WAVE_DW >= 32 * (FN * 16 + 4), "ring too small for the epilogue strip");
+  __builtin_amdgcn_s_barrier();  // all waves are done reading the last K tile (and every DMA has landed: vmcnt(0) above)
+  ring_epilogue_auto<FM, FN>(p, acc, mbase, nbase, lane, reinterpret_cast<uint32_t*>(lds) + wave * WAVE_DW);
 }
 
 // deterministic slab reduction + the usual epilogue (bias, temb row-bias, gate, residual, accumulate)

@@ -1,0 +1,294 @@
+// gemm_tile.h — pieces shared by the LDS-DMA GEMM kernels (gemm_ring.hip, gemm_pers.hip): A-operand addressing for the
+// four loader modes, counted vmcnt waits, and the register-direct epilogue.
+#pragma once
+#include "common.h"
+
+namespace {
+
+__device__ uint4 g_zero_page[4];
+
+struct RowInfo {
+  long off1, off2;
+  int oy, ox;
+  bool valid;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Source address of one 16-byte chunk of the A operand; written with selects (no divergent branches around the DMA).
+template <int MODE>
+LVD_DEV const lvd_bf16* a_src(const lvd_gemm_params& p, const RowInfo& r, int k0, int klim) {
+  const lvd_bf16* z = reinterpret_cast<const lvd_bf16*>(g_zero_page);
+  bool ok = r.valid && k0 < klim;
+  const lvd_bf16* base;
+  long off;
+  if (MODE == LVD_A_PLAIN) {
+    bool s2 = k0 >= p.c1;
+    base = s2 ? p.a2 : p.a1;
+    off = s2 ? r.off2 + (k0 - p.c1) : r.off1 + k0;
+  } else if (MODE == LVD_A_CONV3X3) {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ky = tap / 3, kx = tap - 3 * ky;
+    int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
+    ok = ok && iy >= 0 && iy < p.hin && ix >= 0 && ix < p.win;
+    int ws = p.win >> p.upsample;
+    iy >>= p.upsample; ix >>= p.upsample;
+    long row = r.off1 + (long)iy * ws + ix;
+    bool s2 = c >= p.c1;
+    base = s2 ? p.a2 : p.a1;
+    off = s2 ? row * p.lda2 + (c - p.c1) : row * p.lda1 + c;
+  } else if (MODE == LVD_A_CONV3X3_T2) {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ky = tap / 3, kx = tap - 3 * ky;
+    int ty = r.oy + 1 - ky, tx = r.ox + 1 - kx;
+    ok = ok && ty >= 0 && tx >= 0 && !((ty | tx) & 1);
+    ty >>= 1; tx >>= 1;
+    ok = ok && ty < p.hin && tx < p.win;
+    base = p.a1;
+    off = (r.off1 + (long)ty * p.win + tx) * p.lda1 + c;
+  } else {
+    int tap = k0 / p.cin;
+    int c = k0 - tap * p.cin;
+    int ff = r.oy + tap - 1;
+    ok = ok && ff >= 0 && ff < p.frames;
+    long row = r.off1 + (long)(tap - 1) * p.hw;
+    bool s2 = c >= p.c1;
+    base = s2 ? p.a2 : p.a1;
+    off = s2 ? row * p.lda2 + (c - p.c1) : row * p.lda1 + c;
+  }
+  return ok ? base + off : z;
+}
+
+template <int N>
+LVD_DEV void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Decode token row m into the loader's per-row state (image / y / x for the convolutions, frame for the temporal conv).
+template <int MODE>
+LVD_DEV RowInfo make_row(const lvd_gemm_params& p, int m, bool live) {
+  RowInfo r;
+  r.valid = live && m < p.M;
+  r.off1 = 0; r.off2 = 0; r.oy = 0; r.ox = 0;
+  if (MODE == LVD_A_PLAIN) {
+    r.off1 = (long)m * p.lda1;
+    r.off2 = (long)m * p.lda2;
+  } else if (MODE == LVD_A_CONV3X3 || MODE == LVD_A_CONV3X3_T2) {
+    int plane = p.hout * p.wout;
+    int nimg = m / plane;
+    int rem = m - nimg * plane;
+    r.oy = rem / p.wout;
+    r.ox = rem - r.oy * p.wout;
+    int hs = p.hin, ws = p.win;
+    if (MODE == LVD_A_CONV3X3 && p.upsample) { hs >>= 1; ws >>= 1; }
+    r.off1 = (long)nimg * hs * ws;
+  } else {
+    r.off1 = m;
+    r.oy = (m / p.hw) % p.frames;
+  }
+  return r;
+}
+
+// Epilogue straight from registers.  The MFMAs are issued as D = W_frag · X_frag^T, so lane (l31) owns token row m and
+// every 4 consecutive accumulator registers are 4 consecutive output channels: bias / temb row-bias / gate / residual /
+// GEGLU are applied on 8-byte row-contiguous vectors with no LDS round trip and no barrier.
+template <int FM, int FN>
+LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int l31, int hi) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = mbase + i * 32 + l31;
+    if (m >= p.M) continue;
+    if (p.act == LVD_ACT_GEGLU) {
+      lvd_bf16* orow = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc;
+#pragma unroll
+      for (int b = 0; b < FN / 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nbase + b * 64 + 8 * q + 4 * hi;  // hidden column in the interleaved W'; gate = n + 32
+          if (n + 32 >= p.N) continue;
+          f32x4 h, g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
+          if (p.bias) {
+            h += *reinterpret_cast<const f32x4*>(p.bias + n);
+            g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+          }
+          uint2 o;
+          o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
+          o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+          stg8(orow + (nbase >> 1) + b * 32 + 8 * q + 4 * hi, o);
+        }
+      continue;
+    }
+    const float* rb = p.rowbias ? p.rowbias + (long)(m / p.rows_per_sample) * p.N : nullptr;
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nbase + j * 32 + 8 * q + 4 * hi;
+        if (n >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+        v *= p.alpha;
+        if (p.res) {
+          uint2 r = ldg8(p.res + (long)m * p.ldres + n);
+          v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+        }
+        if (p.out_fp32) {
+          float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+          lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+          if (p.accumulate) {
+            uint2 r = ldg8(o);
+            v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+          }
+          uint2 w;
+          w.x = pack2bf(v[0], v[1]);
+          w.y = pack2bf(v[2], v[3]);
+          stg8(o, w);
+        }
+      }
+  }
+}
+
+// Coalesced epilogue.  The register-direct form above writes 16 bytes per token row per store instruction (32 rows, 32
+// different cache lines): on the short-K layers, where the output is as large as the input, those partial-line stores
+// were the longest phase of the kernel.  Here each wave transposes its accumulators through a private LDS strip
+// (32 rows x W output columns, bf16, after bias / temb row-bias / alpha / GEGLU), then every lane moves 16 bytes so that
+// consecutive lanes cover consecutive bytes of a row: full 128-byte lines for the store and for the residual /
+// accumulate read.  The residual is added in fp32 to the bf16-rounded projection (what the reference's separate
+// residual add does).  Wave-private: no workgroup barrier, the LDS queue keeps one wave's accesses in order.
+template <int FM, int FN, bool GEGLU>
+LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int lane, uint32_t* buf) {
+  constexpr int W = GEGLU ? FN * 16 : FN * 32;  // output columns of this wave
+  constexpr int S = W / 2 + 4;                  // dwords per staged row (16-byte aligned rows, 2-way worst-case write conflict)
+  constexpr int CPR = W / 8;                    // 16-byte chunks per row
+  constexpr int PASSES = (32 * CPR + 63) / 64;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int col0 = GEGLU ? (nbase >> 1) : nbase;
+  const int ncols = GEGLU ? (p.N >> 1) : p.N;
+  lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = mbase + i * 32 + l31;
+    uint32_t* wrow = buf + l31 * S;
+    if (GEGLU) {
+#pragma unroll
+      for (int b = 0; b < FN / 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nbase + b * 64 + 8 * q + 4 * hi;  // hidden column in the interleaved W'; gate = n + 32
+          f32x4 h, g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
+          if (p.bias && n + 32 < p.N) {
+            h += *reinterpret_cast<const f32x4*>(p.bias + n);
+            g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+          }
+          uint2 o;
+          o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
+          o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+          *reinterpret_cast<uint2*>(wrow + b * 16 + 4 * q + 2 * hi) = o;
+        }
+    } else {
+      const int ms = m < p.M ? m : p.M - 1;
+      const float* rb = p.rowbias ? p.rowbias + (long)(ms / p.rows_per_sample) * p.N : nullptr;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nbase + j * 32 + 8 * q + 4 * hi;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+          if (n < p.N) {
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+          }
+          v *= p.alpha;
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(wrow + j * 16 + 4 * q + 2 * hi) = o;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int idx = ps * 64 + lane;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int mm = mbase + i * 32 + r;
+      const int n = col0 + c * 8;
+      if (idx < 32 * CPR && mm < p.M && n < ncols) {
+        uint4 v = *reinterpret_cast<const uint4*>(buf + r * S + c * 4);
+        lvd_bf16* o = out + (long)mm * p.ldc + n;
+        if (p.res || p.accumulate) {
+          float f[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+          if (p.res) {
+            uint4 t = ldg16(p.res + (long)mm * p.ldres + n);
+            f[0] += bflo(t.x); f[1] += bfhi(t.x); f[2] += bflo(t.y); f[3] += bfhi(t.y);
+            f[4] += bflo(t.z); f[5] += bfhi(t.z); f[6] += bflo(t.w); f[7] += bfhi(t.w);
+          }
+          if (p.accumulate) {
+            uint4 t = ldg16(o);
+            f[0] += bflo(t.x); f[1] += bfhi(t.x); f[2] += bflo(t.y); f[3] += bfhi(t.y);
+            f[4] += bflo(t.z); f[5] += bfhi(t.z); f[6] += bflo(t.w); f[7] += bfhi(t.w);
+          }
+          v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+        }
+        stg16(o, v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// true when the coalesced epilogue applies: bf16 output whose rows (and the residual's) are 16-byte addressable
+LVD_DEV bool rows_epilogue_ok(const lvd_gemm_params& p) {
+  bool ok = !p.out_fp32 && (p.N & 15) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+  if (p.res) ok = ok && (p.ldres & 7) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0;
+  return ok;
+}
+
+template <int FM, int FN>
+LVD_DEV void ring_epilogue_auto(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int lane, uint32_t* buf) {
+  if (rows_epilogue_ok(p)) {
+    if (p.act == LVD_ACT_GEGLU) {
+      if constexpr (FN % 2 == 0) ring_epilogue_rows<FM, FN, true>(p, acc, mbase, nbase, lane, buf);
+    } else {
+      ring_epilogue_rows<FM, FN, false>(p, acc, mbase, nbase, lane, buf);
+    }
+  } else {
+    ring_epilogue<FM, FN>(p, acc, mbase, nbase, lane & 31, lane >> 5);
+  }
+}
+
+}  // namespace
