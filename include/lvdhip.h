@@ -58,7 +58,13 @@ enum {
   LVD_GEMM_V_RING256W = 11, /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
   LVD_GEMM_V_RING256K64 = 14, /* 256x256x64 LDS-DMA double buffer, 8 waves */
   LVD_GEMM_V_RING128x320 = 17, /* 128x320x32 LDS-DMA double buffer (N = 320·k exactly), 2 workgroups/CU */
-  LVD_GEMM_V_SPLITK = 20     /* 128x128x32 ring, K split over workgroups + deterministic slab reduction (under-filled grids) */
+  LVD_GEMM_V_SPLITK = 20,    /* 128x128x32 ring, K split over workgroups + deterministic slab reduction (under-filled grids) */
+  LVD_GEMM_V_PERS256W = 21,  /* persistent tile walker, 256x320 / 256x256, 8 waves (K-tile ring runs through tile boundaries) */
+  LVD_GEMM_V_PERS128x320 = 22, /* persistent, 128x320 / 128x256, 2 workgroups/CU */
+  LVD_GEMM_V_PERS128 = 23,   /* persistent, 128x128, 3 workgroups/CU */
+  LVD_GEMM_V_PERS256N = 24,  /* persistent, 256x160 / 256x128 */
+  LVD_GEMM_V_RING256W_TAIL = 31,   /* RING256W on the rows that fill whole rounds of the 256 CUs, split-K on the remainder */
+  LVD_GEMM_V_RING128x320_TAIL = 37 /* RING128x320 on whole rounds of 512 workgroup slots, split-K on the remainder */
 };
 
 typedef struct {
@@ -88,6 +94,8 @@ typedef struct {
   int32_t ksplit;          /* LVD_GEMM_V_SPLITK only: number of K slices (0 = choose from the grid size) */
   float* ws;               /* split-K workspace, fp32 slabs [ksplit, M, N]; caller-owned */
   int64_t ws_bytes;
+  int32_t m_begin;         /* rows [m_begin, M) are produced (0 = the whole product); row indices stay absolute, so a product
+                              can be cut into row ranges (LVD_GEMM_V_*_TAIL variants do this internally) */
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);

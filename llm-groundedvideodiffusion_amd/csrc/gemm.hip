@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
   bool wvalid[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    int m = tm * BM + r0 + RSTEP * i;
+    int m = p.m_begin + tm * BM + r0 + RSTEP * i;
     ar[i].valid = m < p.M;
     ar[i].off1 = 0; ar[i].off2 = 0; ar[i].oy = 0; ar[i].ox = 0;
     if (MODE == LVD_A_PLAIN) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
   constexpr int RP = BK;             // rows per pass: the wave's LDS share is TILE*2*16/4 bytes = RP rows x 64 fp32
   constexpr int NP = 64 / RP;        // passes (BK=64: 1, BK=32: 2)
   float* S = reinterpret_cast<float*>(lds) + wave * (RP * 64);
-  const int mbase = tm * BM + wm * 64;
+  const int mbase = p.m_begin + tm * BM + wm * 64;
   const int nbase = tn * BN + wn * 64;
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
@@ -291,6 +291,73 @@ int launch_gemm(const lvd_gemm_params* p, dim3 grid, hipStream_t s) {
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_ring.hip
 int lvd_gemm_pers_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_pers.hip
 
+namespace {
+
+// One launch (two for split-K) of a pinned or heuristic tile geometry over rows [m_begin, M).
+int run_variant(const lvd_gemm_params* p, void* stream, int v) {
+  int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
+  dim3 grid(tiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (v == 0) {
+    // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_variants.txt):
+    //   under-filled grids            -> 128x128x64 register-staged (fewest, longest tiles)
+    //   conv / tconv / long-K linear  -> LDS-DMA ring, 3 stages, 3 workgroups per CU
+    //   short-K linear                -> 128x128x32 register-staged, 4 workgroups per CU
+    if (tiles < 400 && p->ws && p->K >= 1024 && p->act == LVD_ACT_NONE) v = 20;  // split-K (falls back if not splittable)
+    else if (tiles < 400) v = 10;
+    else if (p->mode != LVD_A_PLAIN || p->K >= 1024) v = 5;
+    else v = 1;
+  }
+  const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
+  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5);
+  if (v == 14) return lvd_gemm_ring_dispatch(p, stream, 8);
+  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20);
+  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, n320 ? 12 : 0);
+  if (v == 11) return lvd_gemm_ring_dispatch(p, stream, n320 ? 4 : 5);
+  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
+  if (v == 21) return lvd_gemm_pers_dispatch(p, stream, n320 ? 4 : 5);
+  if (v == 22) return lvd_gemm_pers_dispatch(p, stream, n320 ? 12 : 13);
+  if (v == 23) return lvd_gemm_pers_dispatch(p, stream, 0);
+  if (v == 24) return lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
+  if (v == 1) return launch_gemm<32, 3>(p, grid, s);
+  if (v == 2) return launch_gemm<32, 4>(p, grid, s);
+  return launch_gemm<64, 2>(p, grid, s);
+}
+
+// Tail-aware launch.  All tiles of one GEMM cost the same, so a grid of T tiles on S resident workgroup slots runs
+// ceil(T/S) rounds however few tiles the last round holds: 540 tiles of 256x320 on 256 CUs take 3 rounds for 2.1 rounds
+// of work.  The rows that fill whole rounds go to the wide geometry; the remaining rows (less than 0.6 of a round) are a
+// second, K-split launch that spreads them over the whole chip again.  Row ranges are disjoint: results are identical to
+// the unsplit product up to the fp32 summation order of the K slices.
+int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+  }
+  const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
+  const int base = v == LVD_GEMM_V_RING256W_TAIL ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320;
+  const int bm = base == LVD_GEMM_V_RING256W ? 256 : 128;
+  const int bn = n320 ? 320 : (base == LVD_GEMM_V_RING256W ? 256 : 128);
+  const int slots = cus * (base == LVD_GEMM_V_RING256W ? 1 : (n320 ? 2 : 3));
+  const int rows = p->M - p->m_begin;
+  const int tiles_n = (p->N + bn - 1) / bn, tiles_m = (rows + bm - 1) / bm;
+  const long total = (long)tiles_m * tiles_n;
+  const long full = total / slots, rem = total - full * slots;
+  const int head_mt = (int)(full * slots / tiles_n);
+  if (full < 1 || rem == 0 || rem * 10 > (long)slots * 6 || head_mt < 1 || head_mt >= tiles_m) return run_variant(p, stream, base);
+  lvd_gemm_params head = *p, tail = *p;
+  head.M = p->m_begin + head_mt * bm;
+  tail.m_begin = head.M;
+  int rc = run_variant(&head, stream, base);
+  if (rc) return rc;
+  return run_variant(&tail, stream, (p->ws && p->act == LVD_ACT_NONE) ? LVD_GEMM_V_SPLITK : LVD_GEMM_V_RING128);
+}
+
+}  // namespace
+
 extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   LVD_CHECK(p && p->a1 && p->w && p->out, "gemm: null pointer");
   LVD_CHECK(p->M > 0 && p->N > 0 && p->K > 0, "gemm: bad shape M=%d N=%d K=%d", p->M, p->N, p->K);
@@ -304,39 +371,16 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   if (p->mode == LVD_A_CONV3X3 || p->mode == LVD_A_CONV3X3_T2)
     LVD_CHECK(p->K == 9 * p->cin && p->hout > 0 && p->wout > 0 && p->hin > 0 && p->win > 0 && p->M % (p->hout * p->wout) == 0,
               "gemm: bad conv dims");
-  int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
-  dim3 grid(tiles);
-  hipStream_t s = (hipStream_t)stream;
+  LVD_CHECK(p->m_begin >= 0 && p->m_begin < p->M, "gemm: m_begin %d outside [0, M=%d)", p->m_begin, p->M);
   static int variant = -1;
   if (variant < 0) {
     const char* e = getenv("LVD_GEMM_VARIANT");  // developer knob for A/B runs (tools/gemm_bench.py)
     variant = e ? atoi(e) : 0;
   }
   int v = p->variant ? p->variant : variant;
-  if (v == 0) {
-    // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_variants.txt):
-    //   under-filled grids            -> 128x128x64 register-staged (fewest, longest tiles)
-    //   conv / tconv / long-K linear  -> LDS-DMA ring, 3 stages, 3 workgroups per CU
-    //   short-K linear                -> 128x128x32 register-staged, 4 workgroups per CU
-    if (tiles < 400 && p->ws && p->K >= 1024 && p->act == LVD_ACT_NONE) v = 20;  // split-K (falls back if not splittable)
-    else if (tiles < 400) v = 10;
-    else if (p->mode != LVD_A_PLAIN || p->K >= 1024) v = 5;
-    else v = 1;
-  }
   int rc;
-  if (v >= 5 && v <= 8) rc = lvd_gemm_ring_dispatch(p, stream, v - 5);
-  else if (v == 14) rc = lvd_gemm_ring_dispatch(p, stream, 8);
-  else if (v == 20) rc = lvd_gemm_ring_dispatch(p, stream, 20);
-  else if (v == 17) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 12 : 0);
-  else if (v == 11) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
-  else if (v == 9) rc = lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
-  else if (v == 21) rc = lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 4 : 5);
-  else if (v == 22) rc = lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 320 == 0) ? 12 : 13);
-  else if (v == 23) rc = lvd_gemm_pers_dispatch(p, stream, 0);
-  else if (v == 24) rc = lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
-  else if (v == 1) rc = launch_gemm<32, 3>(p, grid, s);
-  else if (v == 2) rc = launch_gemm<32, 4>(p, grid, s);
-  else rc = launch_gemm<64, 2>(p, grid, s);
+  if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
+  else rc = run_variant(p, stream, v);
   LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();
   return 0;

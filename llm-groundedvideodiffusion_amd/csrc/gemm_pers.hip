@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS) void gemm_pers_kernel(const lvd_
     int tm = 0, tn = 0;
     if (live) tile_of(j, tm, tn);
 #pragma unroll
-    for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, tm * BM + (wave * APW + q) * RPI + rsub, live);
+    for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, p.m_begin + tm * BM + (wave * APW + q) * RPI + rsub, live);
 #pragma unroll
     for (int t = 0; t < BPW; ++t) {
       int n = tn * BN + bins[t] * RPI + rsub;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS) void gemm_pers_kernel(const lvd_
     if (++ck == nk) {
       int tm, tn;
       tile_of(cj, tm, tn);
-      ring_epilogue<FM, FN>(p, acc, tm * BM + wm * FM * 32, tn * BN + wn * FN * 32, l31, hi);
+      ring_epilogue<FM, FN>(p, acc, p.m_begin + tm * BM + wm * FM * 32, tn * BN + wn * FN * 32, l31, hi);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -186,7 +186,7 @@ int launch_pers_mode(const lvd_gemm_params* p, hipStream_t s) {
     slots = (cus * occ) & ~7;  // multiple of 8: tile t and workgroup t % G then sit on the same XCD
     if (slots < 8) slots = 8;
   }
-  int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
+  int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   int grid = tiles < slots ? tiles : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), 0, s, *p, tiles);
   return 0;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 
   RowInfo ar[APW];
 #pragma unroll
-  for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, tm * BM + (wave * APW + q) * RPI + rsub, true);
+  for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, p.m_begin + tm * BM + (wave * APW + q) * RPI + rsub, true);
   long woff[BPW];
   bool wvalid[BPW];
   int bins[BPW];
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   }
   wait_vmcnt<0>();
 
-  const int mbase = tm * BM + wm * FM * 32;
+  const int mbase = p.m_begin + tm * BM + wm * FM * 32;
   const int nbase = tn * BN + wn * FN * 32;
   if (SPLITK) {  // raw fp32 partial sums into this slice's slab; bias/residual/... happen in splitk_reduce_kernel
-    float* slab = p.ws + (long)slice * p.M * p.N;
+    float* slab = p.ws + ((long)slice * (p.M - p.m_begin) - p.m_begin) * p.N;  // slabs hold rows [m_begin, M)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = mbase + i * 32 + l31;
@@ -192,13 +192,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 
 // deterministic slab reduction + the usual epilogue (bias, temb row-bias, gate, residual, accumulate)
 __global__ void splitk_reduce_kernel(const lvd_gemm_params p) {
-  const long quads = (long)p.M * (p.N >> 2);
-  const long slab = (long)p.M * p.N;
+  const int rows = p.M - p.m_begin;
+  const long quads = (long)rows * (p.N >> 2);
+  const long slab = (long)rows * p.N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / (p.N >> 2));
-    const int n = (int)(i - (long)m * (p.N >> 2)) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (long)m * p.N + n);
-    for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + s * slab + (long)m * p.N + n);
+    const int lm = (int)(i / (p.N >> 2));
+    const int n = (int)(i - (long)lm * (p.N >> 2)) * 4;
+    const int m = p.m_begin + lm;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (long)lm * p.N + n);
+    for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + s * slab + (long)lm * p.N + n);
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
     v *= p.alpha;
@@ -226,14 +228,15 @@ __global__ void splitk_reduce_kernel(const lvd_gemm_params p) {
 
 int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   lvd_gemm_params p = *pp;
-  const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int rows = p.M - p.m_begin;
+  const int tiles = ((rows + 127) / 128) * ((p.N + 127) / 128);
   int ks = p.ksplit;
   if (ks <= 0) {
-    ks = (768 + tiles - 1) / tiles;           // aim at ~3 workgroups per CU
+    ks = 768 / tiles;                         // one full round of 3 workgroups per CU, never a second partial one
     if (ks > p.K / 256) ks = p.K / 256;       // keep >= 8 K tiles per slice
     if (ks > 16) ks = 16;
   }
-  long need = (long)ks * p.M * p.N * 4;
+  long need = (long)ks * rows * p.N * 4;
   if (ks < 2 || p.act != LVD_ACT_NONE || !p.ws || p.ws_bytes < need) return -1;  // caller falls back to the unsplit ring
   p.ksplit = ks;
   dim3 grid(tiles * ks), block(256);
@@ -244,7 +247,7 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
     case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
     default: return 1;
   }
-  long quads = (long)p.M * (p.N / 4);
+  long quads = (long)rows * (p.N / 4);
   int rb = (int)((quads + 255) / 256);
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, p);
@@ -254,7 +257,7 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
 template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32>
 int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
-  int tiles = ((p->M + BM - 1) / BM) * ((p->N + BN - 1) / BN);
+  int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   dim3 grid(tiles), block(64 * WM * WN);
   switch (p->mode) {
     case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;

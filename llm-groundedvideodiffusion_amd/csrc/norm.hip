@@ -16,68 +16,89 @@ LVD_DEV void load4(const lvd_bf16* x1, const lvd_bf16* x2, int ld1, int ld2, int
   uint2 r = (c < c1) ? ldg8(x1 + row * ld1 + c) : ldg8(x2 + row * ld2 + (c - c1));
   v[0] = bflo(r.x); v[1] = bfhi(r.x); v[2] = bflo(r.y); v[3] = bfhi(r.y);
 }
+LVD_DEV void unpack8(uint4 r, float v[8]) {
+  v[0] = bflo(r.x); v[1] = bfhi(r.x); v[2] = bflo(r.y); v[3] = bfhi(r.y);
+  v[4] = bflo(r.z); v[5] = bfhi(r.z); v[6] = bflo(r.w); v[7] = bfhi(r.w);
+}
+LVD_DEV void load8(const lvd_bf16* x1, const lvd_bf16* x2, int ld1, int ld2, int c1, long row, int c, float v[8]) {
+  unpack8((c < c1) ? ldg16(x1 + row * ld1 + c) : ldg16(x2 + row * ld2 + (c - c1)), v);
+}
+
+// Fold the RL row-lanes of a block: red is [RL][VC][16] (8 first-moment, 8 second-moment sums per 8-channel vector).
+LVD_DEV void gn_fold_rows(float* red, float s1[8], float s2[8], int VC, int RL, int vcid, int rl, bool live, float* out) {
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[(rl * VC + vcid) * 16 + e] = s1[e]; red[(rl * VC + vcid) * 16 + 8 + e] = s2[e]; }
+  }
+  __syncthreads();
+  if (live && rl == 0) {
+    for (int q = 1; q < RL; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += red[(q * VC + vcid) * 16 + e]; s2[e] += red[(q * VC + vcid) * 16 + 8 + e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
+  }
+}
+
+// Sum the (chunk, channel-of-group) partial pairs of one (sample, group) with the whole block: independent loads, one
+// memory round trip deep whatever the chunk count.  Returns the totals in every thread.
+LVD_DEV void gn_group_totals(const float* partial, int chunks, int c, int cpg, int s, int g, float& a, float& b) {
+  __shared__ float wsum[2][4];
+  a = 0.f; b = 0.f;
+  const int n = chunks * cpg;
+  const float* base = partial + ((long)s * chunks * c + g * cpg) * 2;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int ch = i / cpg, cc = i - ch * cpg;
+    float2 v = *reinterpret_cast<const float2*>(base + ((long)ch * c + cc) * 2);
+    a += v.x; b += v.y;
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = a; wsum[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+  b = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+}
 
 // ------------------------------------------------------------------ GroupNorm forward stats
-// grid (chunks, samples); block = VC*RL threads (VC = c/4 channel-quads, RL row lanes)
+// grid (chunks, samples); block = VC*RL threads (VC = c/8 channel-octets: 16-byte loads, RL row lanes)
 __global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
-  extern __shared__ float red[];  // [RL][VC][8]
+  extern __shared__ float red[];  // [RL][VC][16]
   const int t = threadIdx.x;
   const int vcid = t % VC, rl = t / VC;
   const int chunk = blockIdx.x, s = blockIdx.y;
   const int rps = p.rows_per_sample;
   const int rpc = (rps + p.chunks - 1) / p.chunks;
   const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
-  const int c = vcid * 4;
-  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  if (rl < RL) {
+  const int c = vcid * 8;
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool live = rl < RL;
+  if (live) {
+#pragma unroll 4
     for (int r = rbeg + rl; r < rend; r += RL) {
-      float v[4];
-      load4(p.x1, p.x2, p.ld1, p.ld2, p.c1, (long)s * rps + r, c, v);
+      float v[8];
+      load8(p.x1, p.x2, p.ld1, p.ld2, p.c1, (long)s * rps + r, c, v);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+      for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { red[(rl * VC + vcid) * 8 + e] = s1[e]; red[(rl * VC + vcid) * 8 + 4 + e] = s2[e]; }
   }
-  __syncthreads();
-  if (rl == 0) {
-    for (int q = 1; q < RL; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += red[(q * VC + vcid) * 8 + e]; s2[e] += red[(q * VC + vcid) * 8 + 4 + e]; }
-    float* out = p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
-  }
+  gn_fold_rows(red, s1, s2, VC, RL, vcid, rl, live, p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2);
 }
 
-// one wave per (sample, group), 4 per block; lanes own channels of the group and walk the chunks with independent
-// (unrolled) loads so the kernel is one memory round trip deep instead of chunks*cpg/64 dependent ones
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const lvd_gn_stats_params p, int total) {
-  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (sg >= total) return;
-  const int s = sg / p.groups, g = sg % p.groups;
+// one 256-thread block per (sample, group)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const lvd_gn_stats_params p) {
+  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
   const int cpg = p.c / p.groups;
-  const int lane = threadIdx.x & 63;
-  float a = 0.f, b = 0.f;
-  for (int cc = lane; cc < cpg; cc += 64) {
-    const float* q = p.partial + ((long)s * p.chunks * p.c + g * cpg + cc) * 2;
-    const long stride = (long)p.c * 2;
-#pragma unroll 8
-    for (int ch = 0; ch < p.chunks; ++ch) {
-      float2 v = *reinterpret_cast<const float2*>(q + ch * stride);
-      a += v.x; b += v.y;
-    }
-  }
-  a = wave_sum(a); b = wave_sum(b);
+  float a, b;
+  gn_group_totals(p.partial, p.chunks, p.c, cpg, s, g, a, b);
   float cnt = (float)cpg * (float)p.rows_per_sample;
   float mean = a / cnt;
   float var = fmaxf(b / cnt - mean * mean, 0.f);
   float rstd = rsqrtf(var + p.eps);
-  if (lane == 0 && p.mean_rstd) {
+  if (threadIdx.x == 0 && p.mean_rstd) {
     p.mean_rstd[((long)s * p.groups + g) * 2] = mean;
     p.mean_rstd[((long)s * p.groups + g) * 2 + 1] = rstd;
   }
-  for (int cc = lane; cc < cpg; cc += 64) {
+  for (int cc = threadIdx.x; cc < cpg; cc += 256) {
     int c = g * cpg + cc;
     float ga = p.gamma[c], be = p.beta[c];
     p.scale_shift[((long)s * p.c + c) * 2] = rstd * ga;
@@ -124,26 +145,27 @@ __global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, i
   const int rps = p.rows_per_sample;
   const int rpc = (rps + p.chunks - 1) / p.chunks;
   const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
-  const int c = vcid * 4;
+  const int c = vcid * 8;
   const int cpg = p.c / p.groups;
-  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  if (rl < RL) {
-    float mean[4], rstd[4], ga[4], be[4];
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool live = rl < RL;
+  if (live) {
+    float mean[8], rstd[8], ga[8], be[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
       int g = (c + e) / cpg;
       mean[e] = p.mean_rstd[((long)s * p.groups + g) * 2];
       rstd[e] = p.mean_rstd[((long)s * p.groups + g) * 2 + 1];
       ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e];
     }
+#pragma unroll 2
     for (int r = rbeg + rl; r < rend; r += RL) {
       long row = (long)s * rps + r;
-      float v[4];
-      load4(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
-      uint2 d = ldg8(p.dy + row * p.lddy + c);
-      float dy[4] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y)};
+      float v[8], dy[8];
+      load8(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
+      unpack8(ldg16(p.dy + row * p.lddy + c), dy);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         float xh = (v[e] - mean[e]) * rstd[e];
         float g = dy[e];
         if (p.silu) g *= silu_grad_f(xh * ga[e] + be[e]);
@@ -151,79 +173,55 @@ __global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, i
         s1[e] += g; s2[e] += g * xh;
       }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { red[(rl * VC + vcid) * 8 + e] = s1[e]; red[(rl * VC + vcid) * 8 + 4 + e] = s2[e]; }
   }
-  __syncthreads();
-  if (rl == 0) {
-    for (int q = 1; q < RL; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += red[(q * VC + vcid) * 8 + e]; s2[e] += red[(q * VC + vcid) * 8 + 4 + e]; }
-    float* out = p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
-  }
+  gn_fold_rows(red, s1, s2, VC, RL, vcid, rl, live, p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2);
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const lvd_gn_bwd_stats_params p, int total) {
-  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (sg >= total) return;
-  const int s = sg / p.groups, g = sg % p.groups;
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const lvd_gn_bwd_stats_params p) {
+  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
   const int cpg = p.c / p.groups;
-  const int lane = threadIdx.x & 63;
-  float a = 0.f, b = 0.f;
-  for (int cc = lane; cc < cpg; cc += 64) {
-    const float* q = p.partial + ((long)s * p.chunks * p.c + g * cpg + cc) * 2;
-    const long stride = (long)p.c * 2;
-#pragma unroll 8
-    for (int ch = 0; ch < p.chunks; ++ch) {
-      float2 v = *reinterpret_cast<const float2*>(q + ch * stride);
-      a += v.x; b += v.y;
-    }
-  }
-  a = wave_sum(a); b = wave_sum(b);
+  float a, b;
+  gn_group_totals(p.partial, p.chunks, p.c, cpg, s, g, a, b);
   float cnt = (float)cpg * (float)p.rows_per_sample;
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     p.gsum[((long)s * p.groups + g) * 2] = a / cnt;
     p.gsum[((long)s * p.groups + g) * 2 + 1] = b / cnt;
   }
 }
 
 __global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p) {
-  const int vpr = p.c >> 2;  // 4-channel vectors
+  const int vpr = p.c >> 3;  // 8-channel vectors
   const int cpg = p.c / p.groups;
   const long total = (long)p.rows * vpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long row = i / vpr;
-    int c = (int)(i - row * vpr) * 4;
+    int c = (int)(i - row * vpr) * 8;
     int s = (int)(row / p.rows_per_sample);
-    float v[4];
-    load4(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
-    uint2 d = ldg8(p.dy + row * p.lddy + c);
-    float dy[4] = {bflo(d.x), bfhi(d.x), bflo(d.y), bfhi(d.y)};
-    float dx[4];
+    float v[8], dy[8], dx[8];
+    load8(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
+    unpack8(ldg16(p.dy + row * p.lddy + c), dy);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
       int g = (c + e) / cpg;
-      float mean = p.mean_rstd[((long)s * p.groups + g) * 2];
-      float rstd = p.mean_rstd[((long)s * p.groups + g) * 2 + 1];
-      float m1 = p.gsum[((long)s * p.groups + g) * 2];
-      float m2 = p.gsum[((long)s * p.groups + g) * 2 + 1];
+      float2 mr = *reinterpret_cast<const float2*>(p.mean_rstd + ((long)s * p.groups + g) * 2);
+      float2 gs = *reinterpret_cast<const float2*>(p.gsum + ((long)s * p.groups + g) * 2);
       float ga = p.gamma[c + e], be = p.beta[c + e];
-      float xh = (v[e] - mean) * rstd;
+      float xh = (v[e] - mr.x) * mr.y;
       float gg = dy[e];
       if (p.silu) gg *= silu_grad_f(xh * ga + be);
       gg *= ga;
-      dx[e] = rstd * (gg - m1 - xh * m2);
+      dx[e] = mr.y * (gg - gs.x - xh * gs.y);
     }
     lvd_bf16* o = (c < p.c1) ? (p.dx1 + row * p.lddx1 + c) : (p.dx2 + row * p.lddx2 + (c - p.c1));
     if (p.accumulate) {
-      uint2 r = ldg8(o);
-      dx[0] += bflo(r.x); dx[1] += bfhi(r.x); dx[2] += bflo(r.y); dx[3] += bfhi(r.y);
+      float r[8];
+      unpack8(ldg16(o), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dx[e] += r[e];
     }
-    uint2 w;
-    w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]);
-    stg8(o, w);
+    uint4 w;
+    w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]); w.z = pack2bf(dx[4], dx[5]); w.w = pack2bf(dx[6], dx[7]);
+    stg16(o, w);
   }
 }
 
@@ -320,9 +318,9 @@ __global__ void ln_bwd_kernel(const lvd_ln_bwd_params p) {
 }
 
 int gn_geometry(int c, int* VC, int* RL, int* threads) {
-  *VC = c / 4;
+  *VC = c / 8;
   if (*VC > 1024) return 1;
-  *RL = 256 / *VC;
+  *RL = 512 / *VC;
   if (*RL < 1) *RL = 1;
   *threads = ((*VC * *RL + 63) / 64) * 64;
   return 0;
@@ -339,9 +337,9 @@ extern "C" int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream
   LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_stats: c too large");
   int samples = p->rows / p->rows_per_sample;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 8 * sizeof(float), s, *p, VC, RL);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 16 * sizeof(float), s, *p, VC, RL);
   LVD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((samples * p->groups + 3) / 4), dim3(256), 0, s, *p, samples * p->groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(samples * p->groups), dim3(256), 0, s, *p);
   LVD_LAUNCH_CHECK();
   return 0;
 }
@@ -364,9 +362,9 @@ extern "C" int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void
   LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_bwd_stats: c too large");
   int samples = p->rows / p->rows_per_sample;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 8 * sizeof(float), s, *p, VC, RL);
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 16 * sizeof(float), s, *p, VC, RL);
   LVD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((samples * p->groups + 3) / 4), dim3(256), 0, s, *p, samples * p->groups);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(samples * p->groups), dim3(256), 0, s, *p);
   LVD_LAUNCH_CHECK();
   return 0;
 }
@@ -374,7 +372,7 @@ extern "C" int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void
 extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream) {
   LVD_CHECK(p && p->x1 && p->dy && p->dx1 && p->gsum, "gn_bwd_apply: null pointer");
   LVD_CHECK(p->x2 == nullptr || p->dx2 != nullptr, "gn_bwd_apply: dx2 missing");
-  long total = (long)p->rows * (p->c / 4);
+  long total = (long)p->rows * (p->c / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);

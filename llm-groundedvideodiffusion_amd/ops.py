@@ -58,6 +58,7 @@ class ConvGeom:
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
 GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17)
 SPLITK_VARIANT = 20
+TAIL_VARIANTS = (31, 37)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
 _splitk_ws = {}
 
 
@@ -90,7 +91,7 @@ def _tune_gemm(p, key, out):
     saved_out, saved_acc = p.out, p.accumulate
     p.out, p.accumulate = scratch.data_ptr(), 0
     best, best_t = 0, float("inf")
-    cands = GEMM_CANDIDATES + ((SPLITK_VARIANT,) if p.ws else ())
+    cands = GEMM_CANDIDATES + ((SPLITK_VARIANT,) + TAIL_VARIANTS if p.ws else ())
     for v in cands:
         p.variant = v
         _launch_gemm(p)  # warm-up (also instruction-cache / L2)
@@ -110,8 +111,8 @@ def _tune_gemm(p, key, out):
 
 def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sample=0, res=None, out=None,
          mode=A_PLAIN, conv: Optional[ConvGeom] = None, frames=0, hw=0, cin=None, act=ACT_NONE, out_fp32=False,
-         alpha=1.0, accumulate=False, m=None, variant=0):
-    """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`."""
+         alpha=1.0, accumulate=False, m=None, variant=0, m_begin=0):
+    """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`.  `m_begin` > 0 produces rows [m_begin, M) only."""
     _chk_bf16(a1, a2, w, res)
     _chk_f32(bias, rowbias)
     N, K = w.shape if (n is None or k is None) else (n, k)
@@ -140,11 +141,14 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     p.ldres = _ld(res) if res is not None else 0
     p.ldc = _ld(out)
     p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
+    p.m_begin = m_begin
     tiles = ((m + 127) // 128) * ((N + 127) // 128)
-    if act == ACT_NONE and tiles < 512 and K >= 1024:  # under-filled grid: offer the split-K path a workspace
-        ws = _splitk_workspace(a1.device, 16 * m * N * 4)
+    if act == ACT_NONE and K >= 512:
+        # split-K workspace: the whole product when the grid is under-filled, otherwise only the last partial round of
+        # tiles is ever split (gemm.hip run_with_tail): <= ~768 slabs of 128x128 fp32
+        ws = _splitk_workspace(a1.device, 16 * m * N * 4 if tiles < 512 else 64 << 20)
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    if variant == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"] and not torch.cuda.is_current_stream_capturing():
+    if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"] and not torch.cuda.is_current_stream_capturing():
         key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample) if conv is not None else None, int(out_fp32))
         variant = _gemm_choice.get(key) or _tune_gemm(p, key, out)
     p.variant = variant

@@ -335,7 +335,27 @@ def test_elementwise():
     assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
 
 
-@pytest.mark.parametrize("variant", [21, 22, 23, 24])
+@pytest.mark.parametrize("variant", [1, 5, 11, 20, 21])
+def test_gemm_row_range(variant):
+    """m_begin: only rows [m_begin, M) are produced, with absolute row indices (temb row-bias, conv geometry)."""
+    M, N, K, rps, mb = 1000, 320, 1032, 250, 389
+    a, w = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4, scale=0.05))
+    bias, rowb, res = rnd(N, seed=5), rnd(M // rps, N, seed=6), bf(rnd(M, N, seed=7))
+    ref = res.float() + a.float() @ w.float().T + bias + rowb.repeat_interleave(rps, 0)
+    out = torch.full((M, N), 7.0, device=DEV).bfloat16()
+    ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, out=out, variant=variant, m_begin=mb)
+    close(out[mb:], ref[mb:], 6e-3, f"v{variant} rows >= m_begin")
+    assert (out[:mb].float() == 7.0).all(), "rows below m_begin were written"
+    n, c, h, wd = 4, 32, 12, 20
+    x, wt = rnd(n, c, h, wd, seed=11), rnd(64, c, 3, 3, seed=12, scale=0.05)
+    refc = to_tokens(F.conv2d(bf(x).float(), bf(wt).float(), padding=1))
+    outc = torch.zeros(n * h * wd, 64, device=DEV).bfloat16()
+    ops.gemm(bf(to_tokens(x)), pack_conv(wt), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), out=outc, variant=variant, m_begin=500)
+    close(outc[500:], refc[500:], 6e-3, f"v{variant} conv rows >= m_begin")
+    assert (outc[:500] == 0).all()
+
+
+@pytest.mark.parametrize("variant", [21, 22, 23, 24, 31, 37])
 def test_gemm_persistent_walks_many_tiles(variant):
     """Persistent variants with far more output tiles than resident workgroups (every workgroup walks several tiles, the
     K-tile ring runs through the tile boundaries): short and ragged K, ragged M, full epilogue, conv loader."""
@@ -359,7 +379,7 @@ def test_gemm_persistent_walks_many_tiles(variant):
     close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{variant} persistent conv")
 
 
-@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 21, 22, 23, 24])
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 21, 22, 23, 24, 31, 37])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
     epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
