@@ -55,14 +55,10 @@ enum {
   LVD_GEMM_V_RING128 = 5,   /* 128x128x32 LDS-DMA ring (3 stages), 3 workgroups/CU */
   LVD_GEMM_V_RING256N = 9,  /* 256x160 / 256x128 LDS-DMA ring, 4 waves */
   LVD_GEMM_V_REG64 = 10,    /* 128x128x64 register-staged, 2 workgroups/CU */
-  LVD_GEMM_V_RING256W = 11, /* 256x320 / 256x256 LDS-DMA ring, 8 waves, 1 workgroup/CU */
+  LVD_GEMM_V_RING256W = 11, /* 256x320 / 256x256 LDS-DMA ring, 8 waves in two ping-pong groups, 1 workgroup/CU */
   LVD_GEMM_V_RING256K64 = 14, /* 256x256x64 LDS-DMA double buffer, 8 waves */
   LVD_GEMM_V_RING128x320 = 17, /* 128x320x32 LDS-DMA double buffer (N = 320·k exactly), 2 workgroups/CU */
   LVD_GEMM_V_SPLITK = 20,    /* 128x128x32 ring, K split over workgroups + deterministic slab reduction (under-filled grids) */
-  LVD_GEMM_V_PERS256W = 21,  /* persistent tile walker, 256x320 / 256x256, 8 waves (K-tile ring runs through tile boundaries) */
-  LVD_GEMM_V_PERS128x320 = 22, /* persistent, 128x320 / 128x256, 2 workgroups/CU */
-  LVD_GEMM_V_PERS128 = 23,   /* persistent, 128x128, 3 workgroups/CU */
-  LVD_GEMM_V_PERS256N = 24,  /* persistent, 256x160 / 256x128 */
   LVD_GEMM_V_RING256W_TAIL = 31,   /* RING256W on the rows that fill whole rounds of the 256 CUs, split-K on the remainder */
   LVD_GEMM_V_RING128x320_TAIL = 37 /* RING128x320 on whole rounds of 512 workgroup slots, split-K on the remainder */
 };

@@ -289,7 +289,6 @@ int launch_gemm(const lvd_gemm_params* p, dim3 grid, hipStream_t s) {
 }  // namespace
 
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_ring.hip
-int lvd_gemm_pers_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_pers.hip
 
 namespace {
 
@@ -315,10 +314,6 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   if (v == 17) return lvd_gemm_ring_dispatch(p, stream, n320 ? 12 : 0);
   if (v == 11) return lvd_gemm_ring_dispatch(p, stream, n320 ? 4 : 5);
   if (v == 9) return lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
-  if (v == 21) return lvd_gemm_pers_dispatch(p, stream, n320 ? 4 : 5);
-  if (v == 22) return lvd_gemm_pers_dispatch(p, stream, n320 ? 12 : 13);
-  if (v == 23) return lvd_gemm_pers_dispatch(p, stream, 0);
-  if (v == 24) return lvd_gemm_pers_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
   if (v == 1) return launch_gemm<32, 3>(p, grid, s);
   if (v == 2) return launch_gemm<32, 4>(p, grid, s);
   return launch_gemm<64, 2>(p, grid, s);

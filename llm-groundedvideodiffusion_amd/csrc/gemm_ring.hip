@@ -22,7 +22,7 @@
 namespace {
 
 // WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
-template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false>
+template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
   constexpr int NW = WM * WN;
   constexpr int RCH = RBK / 8;                            // 16-byte chunks per tile row (4: 64 B rows, 8: full 128 B lines)
@@ -118,46 +118,102 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) stage(s, s);
 
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most (STAGES-2) younger stages are still outstanding
+  if constexpr (PP) {
+    // Ping-pong schedule for the 8-wave geometries (two waves per SIMD).  In the lock-step loop below both waves of a
+    // SIMD read their fragments at the same time and then compete for the MFMA pipe at the same time.  Here the K tile
+    // is two phases — L: fragments LDS -> registers, refill DMA, waits;  M: nothing but MFMAs — and waves 4-7 run one
+    // phase behind waves 0-3 (one extra barrier in front, one behind), so every SIMD always has one wave in M.
+    //   RAW: a wave waits for ITS share of tile kt+1 at the end of L(kt); both groups have done so before the barrier
+    //        that precedes the first L(kt+1).
+    //   WAR: the refill issued in L(kt) overwrites tile kt-1, last read in the other group's L(kt-1) one phase earlier
+    //        and retired there by lgkmcnt(0) before the barrier.
+    const int group = wave >> 2;
     wait_vmcnt<(STAGES - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
-    // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1, one DMA instruction every IVL MFMAs: the
-    // address arithmetic hides in the MFMA shadow and the L2 sees a steady request stream instead of a burst per barrier.
-    const int nslot = slot == 0 ? STAGES - 1 : slot - 1;
-    constexpr int NMF = (RBK / 16) * FM * FN;            // MFMAs per wave per K tile
-    constexpr int IVL = NMF / LPS > 0 ? NMF / LPS : 1;   // one DMA instruction every IVL MFMAs: a steady request stream
-    const uint4* A = lds + slot * TILE;
-    const uint4* B = A + BM * RCH;
+    if (group == 1) __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nslot = slot == 0 ? STAGES - 1 : slot - 1;
+      const uint4* A = lds + slot * TILE;
+      const uint4* B = A + BM * RCH;
+      bf16x8 af[RBK / 16][FM], bfr[RBK / 16][FN];
 #pragma unroll
-    for (int ks = 0; ks < RBK / 16; ++ks) {
-      bf16x8 af[FM], bfr[FN];
-      const int c = ks * 2 + hi;
+      for (int ks = 0; ks < RBK / 16; ++ks) {
+        const int c = ks * 2 + hi;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        int row = (wm * FM + i) * 32 + l31;
-        af[i] = as_bf16x8(A[row * RCH + swz(row, c)]);
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        int row = (wn * FN + j) * 32 + l31;
-        bfr[j] = as_bf16x8(B[row * RCH + swz(row, c)]);
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) {
+          int row = (wm * FM + i) * 32 + l31;
+          af[ks][i] = as_bf16x8(A[row * RCH + swz(row, c)]);
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          const int cnt = (ks * FM + i) * FN + j;
-          if (cnt % IVL == 0 && cnt / IVL < LPS) stage_one(kt + STAGES - 1, nslot, cnt / IVL);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = token row
+          int row = (wn * FN + j) * 32 + l31;
+          bfr[ks][j] = as_bf16x8(B[row * RCH + swz(row, c)]);
         }
-    }
-    if (LPS > NMF) {
+      }
+      stage(kt + STAGES - 1, nslot);
+      wait_vmcnt<(STAGES - 2) * LPS>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int idx = NMF; idx < LPS; ++idx) stage_one(kt + STAGES - 1, nslot, idx);
+      for (int ks = 0; ks < RBK / 16; ++ks)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
-    slot = slot + 1 == STAGES ? 0 : slot + 1;
+    if (group == 0) __builtin_amdgcn_s_barrier();
+  } else {
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed once at most (STAGES-2) younger stages are still outstanding
+      wait_vmcnt<(STAGES - 2) * LPS>();
+      __builtin_amdgcn_s_barrier();
+      // refill the slot consumed in iteration kt-1 with tile kt+STAGES-1, one DMA instruction every IVL MFMAs: the
+      // address arithmetic hides in the MFMA shadow and the L2 sees a steady request stream instead of a burst per barrier.
+      const int nslot = slot == 0 ? STAGES - 1 : slot - 1;
+      constexpr int NMF = (RBK / 16) * FM * FN;            // MFMAs per wave per K tile
+      constexpr int IVL = NMF / LPS > 0 ? NMF / LPS : 1;   // one DMA instruction every IVL MFMAs: a steady request stream
+      const uint4* A = lds + slot * TILE;
+      const uint4* B = A + BM * RCH;
+  #pragma unroll
+      for (int ks = 0; ks < RBK / 16; ++ks) {
+        bf16x8 af[FM], bfr[FN];
+        const int c = ks * 2 + hi;
+  #pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          int row = (wm * FM + i) * 32 + l31;
+          af[i] = as_bf16x8(A[row * RCH + swz(row, c)]);
+        }
+  #pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          int row = (wn * FN + j) * 32 + l31;
+          bfr[j] = as_bf16x8(B[row * RCH + swz(row, c)]);
+        }
+  #pragma unroll
+        for (int i = 0; i < FM; ++i)
+  #pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int cnt = (ks * FM + i) * FN + j;
+            if (cnt % IVL == 0 && cnt / IVL < LPS) stage_one(kt + STAGES - 1, nslot, cnt / IVL);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = token row
+          }
+      }
+      if (LPS > NMF) {
+  #pragma unroll
+        for (int idx = NMF; idx < LPS; ++idx) stage_one(kt + STAGES - 1, nslot, idx);
+      }
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
   }
   wait_vmcnt<0>();
 
@@ -254,16 +310,16 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   return 0;
 }
 
-template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32>
+template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32, bool PP = false>
 int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   dim3 grid(tiles), block(64 * WM * WN);
   switch (p->mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
-    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, RBK>), grid, block, 0, s, *p); break;
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
     default: return 1;
   }
   return 0;
@@ -272,7 +328,8 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
 }  // namespace
 
 // geometry: 0 = 128x128 (3 stages), 1 = 128x128 (4 stages), 2 = 256x160 (3 stages), 3 = 256x128 (3 stages),
-//           4 = 256x320 8 waves (3 stages), 5 = 256x256 8 waves (3 stages), 8 = 256x256x64 8 waves (2 stages)
+//           4 = 256x320 8 waves (3 stages, ping-pong), 5 = 256x256 8 waves (3 stages, ping-pong),
+//           8 = 256x256x64 8 waves (2 stages), 12 = 128x320 (2 stages), 20 = split-K 128x128
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
   hipStream_t s = (hipStream_t)stream;
   if (geometry == 20) {
@@ -285,8 +342,8 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
     case 1: return launch_ring<2, 2, 2, 2, 4>(p, s);
     case 2: return launch_ring<4, 1, 2, 5, 3>(p, s);
     case 3: return launch_ring<4, 1, 2, 4, 3>(p, s);
-    case 4: return launch_ring<4, 2, 2, 5, 3>(p, s);
-    case 5: return launch_ring<4, 2, 2, 4, 3>(p, s);
+    case 4: return launch_ring<4, 2, 2, 5, 3, 32, true>(p, s);
+    case 5: return launch_ring<4, 2, 2, 4, 3, 32, true>(p, s);
     case 8: return launch_ring<4, 2, 2, 4, 2, 64>(p, s);
     case 12: return launch_ring<2, 2, 2, 5, 2>(p, s);
     default: return 1;

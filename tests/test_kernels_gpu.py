@@ -335,7 +335,7 @@ def test_elementwise():
     assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 5, 11, 20, 21])
+@pytest.mark.parametrize("variant", [1, 5, 11, 17, 20])
 def test_gemm_row_range(variant):
     """m_begin: only rows [m_begin, M) are produced, with absolute row indices (temb row-bias, conv geometry)."""
     M, N, K, rps, mb = 1000, 320, 1032, 250, 389
@@ -355,31 +355,31 @@ def test_gemm_row_range(variant):
     assert (outc[:500] == 0).all()
 
 
-@pytest.mark.parametrize("variant", [21, 22, 23, 24, 31, 37])
-def test_gemm_persistent_walks_many_tiles(variant):
-    """Persistent variants with far more output tiles than resident workgroups (every workgroup walks several tiles, the
-    K-tile ring runs through the tile boundaries): short and ragged K, ragged M, full epilogue, conv loader."""
+@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37])
+def test_gemm_many_tiles(variant):
+    """Grids of several rounds of tiles (tail-aware variants split them into whole rounds + a K-split remainder): short and
+    ragged K, ragged M, full epilogue, GEGLU, conv loader."""
     for M, N, K in ((256 * 700 + 37, 320, 328), (128 * 900 + 5, 640, 72)):
         a, w = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4, scale=0.05))
         bias, res = rnd(N, seed=5), bf(rnd(M, N, seed=7))
         ref = res.float() + a.float() @ w.float().T + bias
         for rep in range(3):
-            close(ops.gemm(a, w, bias=bias, res=res, variant=variant), ref, 6e-3, f"v{variant} persistent {M}x{N}x{K} run {rep}")
+            close(ops.gemm(a, w, bias=bias, res=res, variant=variant), ref, 6e-3, f"v{variant} many-tiles {M}x{N}x{K} run {rep}")
     ag, wg, bg = bf(rnd(256 * 300 + 9, 320, seed=8)), bf(rnd(1280, 320, seed=9, scale=0.05)), rnd(1280, seed=10)
     proj = ag.float() @ wg.float().T + bg
     from lvd_amd.weights import interleave_geglu
     wi, bi = interleave_geglu(wg, bg)
     close(ops.gemm(ag, bf(wi), bias=bi, act=ops.ACT_GEGLU, variant=variant),
-          proj[:, :640] * F.gelu(proj[:, 640:]), 6e-3, f"v{variant} persistent geglu")
+          proj[:, :640] * F.gelu(proj[:, 640:]), 6e-3, f"v{variant} many-tiles geglu")
     n, c, h, wd = 48, 64, 40, 72
     x = rnd(n, c, h, wd, seed=11)
     wt = rnd(320, c, 3, 3, seed=12, scale=0.05)
     refc = F.conv2d(bf(x).float(), bf(wt).float(), padding=1)
     out = ops.gemm(bf(to_tokens(x)), pack_conv(wt), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=variant)
-    close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{variant} persistent conv")
+    close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{variant} many-tiles conv")
 
 
-@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 21, 22, 23, 24, 31, 37])
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
     epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
