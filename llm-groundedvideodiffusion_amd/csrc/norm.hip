@@ -107,27 +107,37 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const lvd_gn_stats_par
 }
 
 // ------------------------------------------------------------------ GroupNorm apply (+SiLU)
-__global__ void gn_apply_kernel(const lvd_gn_apply_params p) {
-  const int vpr = p.c >> 3;  // 8-channel vectors per row
-  const long total = (long)p.rows * vpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long row = i / vpr;
-    int c = (int)(i - row * vpr) * 8;
-    int s = (int)(row / p.rows_per_sample);
-    uint4 r = (c < p.c1) ? ldg16(p.x1 + row * p.ld1 + c) : ldg16(p.x2 + row * p.ld2 + (c - p.c1));
+// grid (chunks, samples); block = VC*RL threads: a thread keeps the scale/shift of its 8 channels in registers and walks rows
+__global__ void gn_apply_kernel(const lvd_gn_apply_params p, int VC, int RL, int chunks) {
+  const int t = threadIdx.x;
+  const int vcid = t % VC, rl = t / VC;
+  if (rl >= RL) return;
+  const int chunk = blockIdx.x, s = blockIdx.y;
+  const int rps = p.rows_per_sample;
+  const int rpc = (rps + chunks - 1) / chunks;
+  const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
+  const int c = vcid * 8;
+  float sc[8], sh[8];
+  {
     const float* ss = p.scale_shift + ((long)s * p.c + c) * 2;
-    f32x4 q0 = *reinterpret_cast<const f32x4*>(ss);
-    f32x4 q1 = *reinterpret_cast<const f32x4*>(ss + 4);
-    f32x4 q2 = *reinterpret_cast<const f32x4*>(ss + 8);
-    f32x4 q3 = *reinterpret_cast<const f32x4*>(ss + 12);
-    float y[8];
-    y[0] = bflo(r.x) * q0[0] + q0[1]; y[1] = bfhi(r.x) * q0[2] + q0[3];
-    y[2] = bflo(r.y) * q1[0] + q1[1]; y[3] = bfhi(r.y) * q1[2] + q1[3];
-    y[4] = bflo(r.z) * q2[0] + q2[1]; y[5] = bfhi(r.z) * q2[2] + q2[3];
-    y[6] = bflo(r.w) * q3[0] + q3[1]; y[7] = bfhi(r.w) * q3[2] + q3[3];
-    if (p.silu) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(ss + 4 * q);
+      sc[2 * q] = v[0]; sh[2 * q] = v[1]; sc[2 * q + 1] = v[2]; sh[2 * q + 1] = v[3];
+    }
+  }
+  const bool first = c < p.c1;
+  const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
+  const int ldx = first ? p.ld1 : p.ld2;
+#pragma unroll 4
+  for (int r = rbeg + rl; r < rend; r += RL) {
+    const long row = (long)s * rps + r;
+    float y[8];
+    unpack8(ldg16(xb + row * ldx), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      y[e] = y[e] * sc[e] + sh[e];
+      if (p.silu) y[e] = silu_f(y[e]);
     }
     uint4 o;
     o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]); o.z = pack2bf(y[4], y[5]); o.w = pack2bf(y[6], y[7]);
@@ -189,35 +199,50 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const lvd_gn_bwd_s
   }
 }
 
-__global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p) {
-  const int vpr = p.c >> 3;  // 8-channel vectors
+__global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p, int VC, int RL, int chunks) {
+  const int t = threadIdx.x;
+  const int vcid = t % VC, rl = t / VC;
+  if (rl >= RL) return;
+  const int chunk = blockIdx.x, s = blockIdx.y;
+  const int rps = p.rows_per_sample;
+  const int rpc = (rps + chunks - 1) / chunks;
+  const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
+  const int c = vcid * 8;
   const int cpg = p.c / p.groups;
-  const long total = (long)p.rows * vpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long row = i / vpr;
-    int c = (int)(i - row * vpr) * 8;
-    int s = (int)(row / p.rows_per_sample);
+  float mean[8], rstd[8], m1[8], m2[8], ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = (c + e) / cpg;
+    float2 mr = *reinterpret_cast<const float2*>(p.mean_rstd + ((long)s * p.groups + g) * 2);
+    float2 gs = *reinterpret_cast<const float2*>(p.gsum + ((long)s * p.groups + g) * 2);
+    mean[e] = mr.x; rstd[e] = mr.y; m1[e] = gs.x; m2[e] = gs.y;
+    ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e];
+  }
+  const bool first = c < p.c1;
+  const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
+  const int ldx = first ? p.ld1 : p.ld2;
+  lvd_bf16* ob = first ? p.dx1 + c : p.dx2 + (c - p.c1);
+  const int ldo = first ? p.lddx1 : p.lddx2;
+#pragma unroll 2
+  for (int r = rbeg + rl; r < rend; r += RL) {
+    const long row = (long)s * rps + r;
     float v[8], dy[8], dx[8];
-    load8(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
+    unpack8(ldg16(xb + row * ldx), v);
     unpack8(ldg16(p.dy + row * p.lddy + c), dy);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int g = (c + e) / cpg;
-      float2 mr = *reinterpret_cast<const float2*>(p.mean_rstd + ((long)s * p.groups + g) * 2);
-      float2 gs = *reinterpret_cast<const float2*>(p.gsum + ((long)s * p.groups + g) * 2);
-      float ga = p.gamma[c + e], be = p.beta[c + e];
-      float xh = (v[e] - mr.x) * mr.y;
+      float xh = (v[e] - mean[e]) * rstd[e];
       float gg = dy[e];
-      if (p.silu) gg *= silu_grad_f(xh * ga + be);
-      gg *= ga;
-      dx[e] = mr.y * (gg - gs.x - xh * gs.y);
+      if (p.silu) gg *= silu_grad_f(xh * ga[e] + be[e]);
+      gg *= ga[e];
+      dx[e] = rstd[e] * (gg - m1[e] - xh * m2[e]);
     }
-    lvd_bf16* o = (c < p.c1) ? (p.dx1 + row * p.lddx1 + c) : (p.dx2 + row * p.lddx2 + (c - p.c1));
+    lvd_bf16* o = ob + row * ldo;
     if (p.accumulate) {
-      float r[8];
-      unpack8(ldg16(o), r);
+      float q[8];
+      unpack8(ldg16(o), q);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dx[e] += r[e];
+      for (int e = 0; e < 8; ++e) dx[e] += q[e];
     }
     uint4 w;
     w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]); w.z = pack2bf(dx[4], dx[5]); w.w = pack2bf(dx[6], dx[7]);
@@ -317,6 +342,14 @@ __global__ void ln_bwd_kernel(const lvd_ln_bwd_params p) {
   }
 }
 
+// row chunks per sample for the elementwise passes: ~8 workgroups per CU over the whole launch, >= 4 rows per row lane
+int gn_row_chunks(int samples, int rows_per_sample, int RL) {
+  int want = (2048 + samples - 1) / samples;
+  int most = rows_per_sample / (4 * RL);
+  if (want > most) want = most;
+  return want < 1 ? 1 : want;
+}
+
 int gn_geometry(int c, int* VC, int* RL, int* threads) {
   *VC = c / 8;
   if (*VC > 1024) return 1;
@@ -347,10 +380,12 @@ extern "C" int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream
 extern "C" int lvdhip_groupnorm_apply(const lvd_gn_apply_params* p, void* stream) {
   LVD_CHECK(p && p->x1 && p->y && p->scale_shift, "gn_apply: null pointer");
   LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0, "gn_apply: channels must be multiples of 8");
-  long total = (long)p->rows * (p->c / 8);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_CHECK(p->rows % p->rows_per_sample == 0, "gn_apply: rows %% rows_per_sample");
+  int VC, RL, threads;
+  LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_apply: c too large");
+  const int samples = p->rows / p->rows_per_sample;
+  const int chunks = gn_row_chunks(samples, p->rows_per_sample, RL);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, samples), dim3(threads), 0, (hipStream_t)stream, *p, VC, RL, chunks);
   LVD_LAUNCH_CHECK();
   return 0;
 }
@@ -372,10 +407,12 @@ extern "C" int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void
 extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream) {
   LVD_CHECK(p && p->x1 && p->dy && p->dx1 && p->gsum, "gn_bwd_apply: null pointer");
   LVD_CHECK(p->x2 == nullptr || p->dx2 != nullptr, "gn_bwd_apply: dx2 missing");
-  long total = (long)p->rows * (p->c / 8);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->rows % p->rows_per_sample == 0, "gn_bwd_apply: bad shape");
+  int VC, RL, threads;
+  LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_bwd_apply: c too large");
+  const int samples = p->rows / p->rows_per_sample;
+  const int chunks = gn_row_chunks(samples, p->rows_per_sample, RL);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks, samples), dim3(threads), 0, (hipStream_t)stream, *p, VC, RL, chunks);
   LVD_LAUNCH_CHECK();
   return 0;
 }
