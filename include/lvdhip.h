@@ -59,6 +59,7 @@ enum {
   LVD_GEMM_V_RING256K64 = 14, /* 256x256x64 LDS-DMA double buffer, 8 waves */
   LVD_GEMM_V_RING128x320 = 17, /* 128x320x32 LDS-DMA double buffer (N = 320·k exactly), 2 workgroups/CU */
   LVD_GEMM_V_SPLITK = 20,    /* 128x128x32 ring, K split over workgroups + deterministic slab reduction (under-filled grids) */
+  LVD_GEMM_V_SPLITK_WIDE = 25, /* K split on the 8-wave 256x320 / 256x256 geometries (small-M, long-K deep-level layers) */
   LVD_GEMM_V_RING256W_TAIL = 31,   /* RING256W on the rows that fill whole rounds of the 256 CUs, split-K on the remainder */
   LVD_GEMM_V_RING128x320_TAIL = 37 /* RING128x320 on whole rounds of 512 workgroup slots, split-K on the remainder */
 };

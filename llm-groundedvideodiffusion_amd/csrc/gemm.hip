@@ -15,6 +15,7 @@
 // bias / GEGLU / gate / residual are applied on 8-16 byte row-contiguous vectors.
 #include <cstdlib>
 #include "common.h"
+#include "gemm_tile.h"
 
 namespace {
 
@@ -292,6 +293,17 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
 
 namespace {
 
+// 256x320 or 256x256 for the wide split-K: whichever the K-split plan predicts to be faster
+bool wide320_fills_better(const lvd_gemm_params* p) {
+  const int rows = p->M - p->m_begin;
+  auto time_of = [&](int bn) {  // planned cost x tile area = relative time
+    long tiles = (long)((rows + 255) / 256) * ((p->N + bn - 1) / bn), cost = 0;
+    lvd_splitk_plan(tiles, p->K, 256, 256 * bn * 450 / 65536, &cost);
+    return cost * bn;
+  };
+  return time_of(320) <= time_of(256);
+}
+
 // One launch (two for split-K) of a pinned or heuristic tile geometry over rows [m_begin, M).
 int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
@@ -311,6 +323,7 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5);
   if (v == 14) return lvd_gemm_ring_dispatch(p, stream, 8);
   if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20);
+  if (v == LVD_GEMM_V_SPLITK_WIDE) return lvd_gemm_ring_dispatch(p, stream, n320 && wide320_fills_better(p) ? 24 : 25);
   if (v == 17) return lvd_gemm_ring_dispatch(p, stream, n320 ? 12 : 0);
   if (v == 11) return lvd_gemm_ring_dispatch(p, stream, n320 ? 4 : 5);
   if (v == 9) return lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);

@@ -282,25 +282,26 @@ __global__ void splitk_reduce_kernel(const lvd_gemm_params p) {
   }
 }
 
+// K split over workgroups: SLOTS = workgroups resident on the device for this geometry (one full round, never a second
+// partial one).  The wide ping-pong geometries stage 2.2x fewer bytes per flop than 128x128 and are what the small-M
+// deep-level layers (M = 1080 ... 8640, K up to 23040) need once the K split gives them enough workgroups.
+template <int WM, int WN, int FM, int FN, int STAGES, bool PP, int SLOTS>
 int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
+  constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   lvd_gemm_params p = *pp;
   const int rows = p.M - p.m_begin;
-  const int tiles = ((rows + 127) / 128) * ((p.N + 127) / 128);
+  const int tiles = ((rows + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   int ks = p.ksplit;
-  if (ks <= 0) {
-    ks = 768 / tiles;                         // one full round of 3 workgroups per CU, never a second partial one
-    if (ks > p.K / 256) ks = p.K / 256;       // keep >= 8 K tiles per slice
-    if (ks > 16) ks = 16;
-  }
+  if (ks <= 0) ks = lvd_splitk_plan(tiles, p.K, SLOTS, BM * BN * 450 / 65536 * (SLOTS == 256 ? 1 : 0) + (SLOTS == 256 ? 0 : 160), nullptr);
   long need = (long)ks * rows * p.N * 4;
   if (ks < 2 || p.act != LVD_ACT_NONE || !p.ws || p.ws_bytes < need) return -1;  // caller falls back to the unsplit ring
   p.ksplit = ks;
-  dim3 grid(tiles * ks), block(256);
+  dim3 grid(tiles * ks), block(64 * WM * WN);
   switch (p.mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
-    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
-    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
-    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, 2, 2, 2, 2, 3, 32, true>), grid, block, 0, s, p); break;
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
     default: return 1;
   }
   long quads = (long)rows * (p.N / 4);
@@ -333,9 +334,14 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
   hipStream_t s = (hipStream_t)stream;
   if (geometry == 20) {
-    int rc = launch_splitk(p, s);
+    int rc = launch_splitk<2, 2, 2, 2, 3, false, 768>(p, s);
     if (rc >= 0) return rc;
     geometry = 0;  // not splittable (no workspace / GEGLU / too little K): plain 128x128 ring
+  }
+  if (geometry == 24 || geometry == 25) {  // K split on the 8-wave ping-pong geometries (256x320 / 256x256), 1 workgroup per CU
+    int rc = geometry == 24 ? launch_splitk<4, 2, 2, 5, 3, true, 256>(p, s) : launch_splitk<4, 2, 2, 4, 3, true, 256>(p, s);
+    if (rc >= 0) return rc;
+    geometry = geometry == 24 ? 4 : 5;
   }
   switch (geometry) {
     case 0: return launch_ring<2, 2, 2, 2, 3>(p, s);

@@ -291,4 +291,21 @@ LVD_DEV void ring_epilogue_auto(const lvd_gemm_params& p, const f32x16 (&acc)[FM
   }
 }
 
+// K-split planning shared by the split-K launchers and the geometry choice.  Cost of c slices in "K elements of one
+// tile's main loop": rounds of SLOTS resident workgroups, each K/c long plus a fixed fill/drain, plus c fp32 slabs per
+// tile that are written and read back (measured: a 256x256 slab costs about as much as 450 K elements, 128x128 ~160).
+inline int lvd_splitk_plan(long tiles, int K, int slots, int slab_cost, long* cost_out) {
+  int kmax = K / 256 < 16 ? K / 256 : 16;
+  if (kmax < 1) kmax = 1;
+  long best = -1;
+  int ks = 1;
+  for (int c = 1; c <= kmax; ++c) {
+    long rounds = (tiles * c + slots - 1) / slots;
+    long cost = rounds * (K / c + 128) + (c > 1 ? (long)c * slab_cost : 0);
+    if (best < 0 || cost < best) { best = cost; ks = c; }
+  }
+  if (cost_out) *cost_out = best;
+  return ks;
+}
+
 }  // namespace

@@ -58,6 +58,7 @@ class ConvGeom:
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
 GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17)
 SPLITK_VARIANT = 20
+SPLITK_WIDE_VARIANT = 25
 TAIL_VARIANTS = (31, 37)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
 _splitk_ws = {}
 
@@ -91,7 +92,7 @@ def _tune_gemm(p, key, out):
     saved_out, saved_acc = p.out, p.accumulate
     p.out, p.accumulate = scratch.data_ptr(), 0
     best, best_t = 0, float("inf")
-    cands = GEMM_CANDIDATES + ((SPLITK_VARIANT,) + TAIL_VARIANTS if p.ws else ())
+    cands = GEMM_CANDIDATES + ((SPLITK_VARIANT, SPLITK_WIDE_VARIANT) + TAIL_VARIANTS if p.ws else ())
     for v in cands:
         p.variant = v
         _launch_gemm(p)  # warm-up (also instruction-cache / L2)

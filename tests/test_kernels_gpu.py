@@ -421,31 +421,32 @@ def test_gemm_every_tile_geometry(variant):
     close(out, reft, 6e-3, f"v{variant} tconv")
 
 
-def test_gemm_split_k():
+@pytest.mark.parametrize("SPLITK", [20, 25])
+def test_gemm_split_k(SPLITK):
     """Under-filled grids (low-resolution UNet levels, M ~ 1e3, K ~ 1e4) run the K-split ring + deterministic slab
     reduction; same epilogue contract (bias, row-bias, gate, residual, accumulate, fp32 out)."""
     M, N, K, rps = 270, 256, 4096, 90
     a, w = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4, scale=0.03))
     bias, rowb, res = rnd(N, seed=5), rnd(M // rps, N, seed=6), bf(rnd(M, N, seed=7))
     ref = res.float() + 0.5 * (a.float() @ w.float().T + bias + rowb.repeat_interleave(rps, 0))
-    out = ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, alpha=0.5, variant=ops.SPLITK_VARIANT)
-    close(out, ref, 6e-3, "split-K epilogue")
-    out2 = ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, alpha=0.5, variant=ops.SPLITK_VARIANT)
-    assert torch.equal(out, out2), "split-K must be deterministic"
+    out = ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, alpha=0.5, variant=SPLITK)
+    close(out, ref, 6e-3, f"v{SPLITK} split-K epilogue")
+    out2 = ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=rps, res=res, alpha=0.5, variant=SPLITK)
+    assert torch.equal(out, out2), f"v{SPLITK} split-K must be deterministic"
     acc = rnd(M, N, seed=8)
     ref32 = acc + a.float() @ w.float().T
-    ops.gemm(a, w, out=acc, out_fp32=True, accumulate=True, variant=ops.SPLITK_VARIANT)
-    close(acc, ref32, 1e-4, "split-K fp32 accumulate")
+    ops.gemm(a, w, out=acc, out_fp32=True, accumulate=True, variant=SPLITK)
+    close(acc, ref32, 1e-4, f"v{SPLITK} split-K fp32 accumulate")
     n, cin, cout, h, wd = 2, 256, 128, 5, 9
     x = bf(rnd(n, cin, h, wd, seed=1)).float()
     wt = bf(conv_w(cout, cin, 2)).float()
     refc = F.conv2d(x, wt, None, padding=1)
-    out = ops.gemm(bf(to_tokens(x)), pack_conv(wt), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=ops.SPLITK_VARIANT)
-    close(from_tokens(out, n, h, wd), refc, 6e-3, "split-K conv")
+    out = ops.gemm(bf(to_tokens(x)), pack_conv(wt), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=SPLITK)
+    close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{SPLITK} split-K conv")
     Bt, Fr, hw, c = 1, 6, 45, 384
     xt = bf(rnd(Bt * Fr * hw, c, seed=1))
     wtc = bf(rnd(c, c, 3, seed=2, scale=0.03)).float()
     x5 = xt.float().reshape(Bt, Fr, hw, c).permute(0, 3, 1, 2)[..., None]
     reft = F.conv3d(x5, wtc[..., None, None], None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(Bt * Fr * hw, c)
-    out = ops.gemm(xt, bf(wtc.permute(0, 2, 1).reshape(c, 3 * c).contiguous()), mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=ops.SPLITK_VARIANT)
-    close(out, reft, 6e-3, "split-K tconv")
+    out = ops.gemm(xt, bf(wtc.permute(0, 2, 1).reshape(c, 3 * c).contiguous()), mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=SPLITK)
+    close(out, reft, 6e-3, f"v{SPLITK} split-K tconv")
