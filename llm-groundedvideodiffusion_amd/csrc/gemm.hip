@@ -241,6 +241,23 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
       continue;
     }
 
+    // residual / accumulate operands first, all in flight together: the stores below may alias them as far as the
+    // compiler knows, so a load inside the store loop would be chained behind the previous store
+    uint2 rres[RP / 4], racc[RP / 4];
+    if (p.res || (p.accumulate && !p.out_fp32)) {
+#pragma unroll
+      for (int it = 0; it < RP / 4; ++it) {
+        int idx = it * 64 + lane;
+        int row = idx >> 4, cq = idx & 15;
+        int m = mrow0 + row;
+        int n = nbase + cq * 4;
+        const bool ok = m < p.M && n < p.N;
+        rres[it] = make_uint2(0, 0);
+        racc[it] = make_uint2(0, 0);
+        if (ok && p.res) rres[it] = ldg8(p.res + (long)m * p.ldres + n);
+        if (ok && p.accumulate && !p.out_fp32) racc[it] = ldg8(reinterpret_cast<const lvd_bf16*>(p.out) + (long)m * p.ldc + n);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < RP / 4; ++it) {
       int idx = it * 64 + lane;
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
       if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
       v *= p.alpha;
       if (p.res) {
-        uint2 r = ldg8(p.res + (long)m * p.ldres + n);
+        uint2 r = rres[it];
         v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
       }
       if (p.out_fp32) {
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
       } else {
         lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
         if (p.accumulate) {
-          uint2 r = ldg8(o);
+          uint2 r = racc[it];
           v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
         }
         uint2 w;

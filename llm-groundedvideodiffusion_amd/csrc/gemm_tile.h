@@ -197,6 +197,23 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
   for (int i = 0; i < FM; ++i) {
     const int m = mbase + i * 32 + l31;
     uint32_t* wrow = buf + l31 * S;
+    // residual / accumulate operands of this 32-row block: all loads in flight before anything depends on them (the
+    // stores below may alias them as far as the compiler knows, so it would otherwise chain load -> store -> load ...)
+    uint4 rres[PASSES], racc[PASSES];
+    if (p.res || p.accumulate) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = ps * 64 + lane;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const int mm = mbase + i * 32 + r;
+        const int n = col0 + c * 8;
+        const bool ok = idx < 32 * CPR && mm < p.M && n < ncols;
+        rres[ps] = make_uint4(0, 0, 0, 0);
+        racc[ps] = make_uint4(0, 0, 0, 0);
+        if (ok && p.res) rres[ps] = ldg16(p.res + (long)mm * p.ldres + n);
+        if (ok && p.accumulate) racc[ps] = ldg16(out + (long)mm * p.ldc + n);
+      }
+    }
     if (GEGLU) {
 #pragma unroll
       for (int b = 0; b < FN / 2; ++b)
@@ -252,12 +269,12 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
         if (p.res || p.accumulate) {
           float f[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
           if (p.res) {
-            uint4 t = ldg16(p.res + (long)mm * p.ldres + n);
+            uint4 t = rres[ps];
             f[0] += bflo(t.x); f[1] += bfhi(t.x); f[2] += bflo(t.y); f[3] += bfhi(t.y);
             f[4] += bflo(t.z); f[5] += bfhi(t.z); f[6] += bflo(t.w); f[7] += bfhi(t.w);
           }
           if (p.accumulate) {
-            uint4 t = ldg16(o);
+            uint4 t = racc[ps];
             f[0] += bflo(t.x); f[1] += bfhi(t.x); f[2] += bflo(t.y); f[3] += bfhi(t.y);
             f[4] += bflo(t.z); f[5] += bfhi(t.z); f[6] += bflo(t.w); f[7] += bfhi(t.w);
           }
