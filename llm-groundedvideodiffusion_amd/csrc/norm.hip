@@ -129,19 +129,30 @@ __global__ void gn_apply_kernel(const lvd_gn_apply_params p, int VC, int RL, int
   const bool first = c < p.c1;
   const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
   const int ldx = first ? p.ld1 : p.ld2;
-#pragma unroll 4
-  for (int r = rbeg + rl; r < rend; r += RL) {
-    const long row = (long)s * rps + r;
-    float y[8];
-    unpack8(ldg16(xb + row * ldx), y);
+  // four rows per trip: the loads are issued together (the stores may alias them for all the compiler knows)
+  for (int r0 = rbeg + rl; r0 < rend; r0 += 4 * RL) {
+    uint4 raw[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      y[e] = y[e] * sc[e] + sh[e];
-      if (p.silu) y[e] = silu_f(y[e]);
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * RL;
+      raw[u] = make_uint4(0, 0, 0, 0);
+      if (r < rend) raw[u] = ldg16(xb + ((long)s * rps + r) * ldx);
     }
-    uint4 o;
-    o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]); o.z = pack2bf(y[4], y[5]); o.w = pack2bf(y[6], y[7]);
-    stg16(p.y + row * p.ldy + c, o);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * RL;
+      if (r >= rend) break;
+      float y[8];
+      unpack8(raw[u], y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        y[e] = y[e] * sc[e] + sh[e];
+        if (p.silu) y[e] = silu_f(y[e]);
+      }
+      uint4 o;
+      o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]); o.z = pack2bf(y[4], y[5]); o.w = pack2bf(y[6], y[7]);
+      stg16(p.y + ((long)s * rps + r) * p.ldy + c, o);
+    }
   }
 }
 
@@ -223,30 +234,44 @@ __global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p, int VC, int
   const int ldx = first ? p.ld1 : p.ld2;
   lvd_bf16* ob = first ? p.dx1 + c : p.dx2 + (c - p.c1);
   const int ldo = first ? p.lddx1 : p.lddx2;
-#pragma unroll 2
-  for (int r = rbeg + rl; r < rend; r += RL) {
-    const long row = (long)s * rps + r;
-    float v[8], dy[8], dx[8];
-    unpack8(ldg16(xb + row * ldx), v);
-    unpack8(ldg16(p.dy + row * p.lddy + c), dy);
+  for (int r0 = rbeg + rl; r0 < rend; r0 += 2 * RL) {
+    uint4 rx[2], rdy[2], rac[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float xh = (v[e] - mean[e]) * rstd[e];
-      float gg = dy[e];
-      if (p.silu) gg *= silu_grad_f(xh * ga[e] + be[e]);
-      gg *= ga[e];
-      dx[e] = rstd[e] * (gg - m1[e] - xh * m2[e]);
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + u * RL;
+      rx[u] = make_uint4(0, 0, 0, 0); rdy[u] = rx[u]; rac[u] = rx[u];
+      if (r < rend) {
+        const long row = (long)s * rps + r;
+        rx[u] = ldg16(xb + row * ldx);
+        rdy[u] = ldg16(p.dy + row * p.lddy + c);
+        if (p.accumulate) rac[u] = ldg16(ob + row * ldo);
+      }
     }
-    lvd_bf16* o = ob + row * ldo;
-    if (p.accumulate) {
-      float q[8];
-      unpack8(ldg16(o), q);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dx[e] += q[e];
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + u * RL;
+      if (r >= rend) break;
+      float v[8], dy[8], dx[8];
+      unpack8(rx[u], v);
+      unpack8(rdy[u], dy);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = (v[e] - mean[e]) * rstd[e];
+        float gg = dy[e];
+        if (p.silu) gg *= silu_grad_f(xh * ga[e] + be[e]);
+        gg *= ga[e];
+        dx[e] = rstd[e] * (gg - m1[e] - xh * m2[e]);
+      }
+      if (p.accumulate) {
+        float q[8];
+        unpack8(rac[u], q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dx[e] += q[e];
+      }
+      uint4 w;
+      w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]); w.z = pack2bf(dx[4], dx[5]); w.w = pack2bf(dx[6], dx[7]);
+      stg16(ob + ((long)s * rps + r) * ldo, w);
     }
-    uint4 w;
-    w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]); w.z = pack2bf(dx[4], dx[5]); w.w = pack2bf(dx[6], dx[7]);
-    stg16(o, w);
   }
 }
 
