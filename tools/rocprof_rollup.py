@@ -1,19 +1,57 @@
-"""Developer probe: per-kernel roll-up of a rocprofv3 --kernel-trace run (rocpd sqlite output).
-usage: python tools/rocprof_rollup.py <dir with *_results.db> [top_n] [skip_first_fraction]"""
-import glob, sqlite3, sys, collections
+"""Per-kernel / per-class roll-up of a rocprofv3 --kernel-trace run (rocpd sqlite output).
+usage: python tools/rocprof_rollup.py <dir with *_results.db> [top_n] [skip_first_fraction]
+The leading fraction of dispatches (weight init, GEMM autotuning, warm-up) can be skipped."""
+import collections
+import glob
+import sqlite3
+import sys
 
-path = sorted(glob.glob(sys.argv[1] + "/**/*_results.db", recursive=True))[0]
-top_n = int(sys.argv[2]) if len(sys.argv) > 2 else 45
-db = sqlite3.connect(path)
-cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-name_col = "name" if "name" in cols else "kernel_name"
-rows = db.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-skip = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # drop the leading part (weight init, autotuning, warm-up)
-rows = rows[int(len(rows) * skip):]
-agg = collections.defaultdict(lambda: [0, 0])
-for n, s, e in rows:
-    a = agg[n]; a[0] += 1; a[1] += e - s
-tot = sum(a[1] for a in agg.values())
-print(f"# {path}: {len(rows)} dispatches, {tot / 1e6:.1f} ms of kernel time")
-for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top_n]:
-    print(f"{n[:120]:120s} calls={c:6d} total_ms={t / 1e6:8.2f} avg_us={t / c / 1e3:8.1f} {100 * t / tot:5.1f}%")
+CLASSES = [
+    ("GEMM family (gemm.hip, gemm_ring.hip, split-K reduce)", ("gemm_kernel", "gemm_ring_kernel", "splitk_reduce")),
+    ("GroupNorm", ("gn_",)),
+    ("attention fwd/bwd", ("attn_",)),
+    ("LayerNorm", ("ln_",)),
+    ("guidance loss (3 kernels/key)", ("ca_",)),
+    ("elementwise / layout", ("geglu_", "add_kernel", "silu_kernel", "tokens", "upsample2x", "timestep_embedding", "cfg_dpm", "axpy", "reduce_sum")),
+]
+
+
+def main():
+    top_n = int(sys.argv[2]) if len(sys.argv) > 2 else 45
+    skip = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+    dbs = sorted(glob.glob(sys.argv[1] + "/**/*_results.db", recursive=True))
+    if dbs:
+        rows = sqlite3.connect(dbs[0]).execute("select name, start, end from kernels order by start").fetchall()
+    else:  # --output-format csv: *_kernel_trace.csv
+        import csv
+        path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
+        rows = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(path))), key=lambda r: r[1])
+    rows = rows[int(len(rows) * skip):]
+    agg = collections.defaultdict(lambda: [0, 0])
+    for n, s, e in rows:
+        a = agg[n]
+        a[0] += 1
+        a[1] += e - s
+    tot = sum(a[1] for a in agg.values())
+    wall = rows[-1][2] - rows[0][1]
+    print(f"# {len(rows)} dispatches, {tot / 1e6:.1f} ms of kernel time in {wall / 1e6:.1f} ms of wall time")
+    cls = collections.OrderedDict((c[0], [0, 0]) for c in CLASSES)
+    cls["torch housekeeping (fills, copies)"] = [0, 0]
+    for n, (c, t) in agg.items():
+        for title, keys in CLASSES:
+            if any(k in n for k in keys):
+                cls[title][0] += c
+                cls[title][1] += t
+                break
+        else:
+            cls["torch housekeeping (fills, copies)"][0] += c
+            cls["torch housekeeping (fills, copies)"][1] += t
+    for title, (c, t) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+        print(f"{title:58s} calls={c:7d} total_ms={t / 1e6:9.1f} share={100 * t / tot:5.1f}%")
+    print("\ntop kernels:")
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top_n]:
+        print(f"{n[:118]:118s} calls={c:6d} total_ms={t / 1e6:8.2f} avg_us={t / c / 1e3:8.1f} {100 * t / tot:5.1f}%")
+
+
+if __name__ == "__main__":
+    main()
