@@ -306,6 +306,18 @@ int lvdhip_axpy(float* x, const float* g, float scale, int64_t n, void* stream);
 /* deterministic sum of n floats -> out[0] (times scale) */
 int lvdhip_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * VAE decode + tensor2vid, the step after the denoising loop (SURVEY §8f row 1;
+ * models/controllable_pipeline_text_to_video_synth.py:374-400 decode_latents, :66-88 tensor2vid; arithmetic in
+ * diffusers 0.27.2 AutoencoderKL.decode).  The decoder is built from the GEMM / GroupNorm entry points above; these
+ * two cover what is left: the single-head (dim 512) attention of the mid block computes its scores with lvdhip_gemm
+ * (fp32 out) and normalises them here; the last one is VaeImageProcessor.postprocess.
+ * ------------------------------------------------------------------------------------------ */
+/* y[r, :cols] = softmax(x[r, :cols]) ; fp32 in, bf16 out ; cols <= 4096 */
+int lvdhip_softmax_rows(const float* x, int32_t ldx, lvd_bf16* y, int32_t ldy, int32_t rows, int32_t cols, void* stream);
+/* tokens [(f,y,x), ld>=4] bf16 (channels 0..2 = RGB in [-1,1]) -> video fp32 [(f,y,x), 3] = clamp(x/2+0.5, 0, 1) */
+int lvdhip_tokens_to_video(const lvd_bf16* tokens, int32_t ld, float* video, int64_t rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,6 +191,50 @@ __global__ void reduce_sum_kernel(const float* x, long n, float scale, float* ou
   }
 }
 
+// ---- row softmax of an fp32 score matrix -> bf16 probabilities (VAE mid-block attention: one head of dim 512, scores
+// by the GEMM family, AutoencoderKL's Attention block).  One wave per row, scores kept in registers (cols <= 64*SM_MAXV).
+constexpr int SM_MAXV = 64;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, lvd_bf16* __restrict__ y, int ldy, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float v[SM_MAXV];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < SM_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = c < cols ? xr[c] : -3.0e38f;
+    m = fmaxf(m, v[j]);
+  }
+  m = wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < SM_MAXV; ++j) {
+    v[j] = fast_exp2((v[j] - m) * 1.4426950408889634f);
+    s += v[j];
+  }
+  const float inv = 1.f / wave_sum(s);
+  lvd_bf16* yr = y + row * ldy;
+#pragma unroll
+  for (int j = 0; j < SM_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < cols) yr[c] = f2bf(v[j] * inv);
+  }
+}
+
+// ---- decoded image tokens [(f,y,x), >=3 channels] bf16 -> video float32 (f, y, x, 3) in [0,1]:  x/2 + 0.5 clamped
+// (VaeImageProcessor.postprocess + tensor2vid, controllable_pipeline_text_to_video_synth.py:66-88,374-400)
+__global__ void tokens_to_video_kernel(const lvd_bf16* __restrict__ t, int ld, float* __restrict__ video, long rows) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+    uint2 r = ldg8(t + i * ld);
+    float c0 = bflo(r.x), c1 = bfhi(r.x), c2 = bflo(r.y);
+    video[i * 3 + 0] = fminf(fmaxf(c0 * 0.5f + 0.5f, 0.f), 1.f);
+    video[i * 3 + 1] = fminf(fmaxf(c1 * 0.5f + 0.5f, 0.f), 1.f);
+    video[i * 3 + 2] = fminf(fmaxf(c2 * 0.5f + 0.5f, 0.f), 1.f);
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -279,6 +323,23 @@ extern "C" int lvdhip_axpy(float* x, const float* g, float scale, int64_t n, voi
 extern "C" int lvdhip_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream) {
   LVD_CHECK(x && out, "reduce_sum: bad args");
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, ST, x, (long)n, scale, out);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_softmax_rows(const float* x, int32_t ldx, lvd_bf16* y, int32_t ldy, int32_t rows, int32_t cols, void* stream) {
+  LVD_CHECK(x && y && rows > 0 && cols > 0, "softmax_rows: bad arguments");
+  LVD_CHECK(cols <= 64 * SM_MAXV, "softmax_rows: cols=%d > %d", cols, 64 * SM_MAXV);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_tokens_to_video(const lvd_bf16* tokens, int32_t ld, float* video, int64_t rows, void* stream) {
+  LVD_CHECK(tokens && video && rows > 0 && ld >= 4 && ld % 4 == 0, "tokens_to_video: bad arguments (ld=%d)", ld);
+  long blocks = (rows + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tokens_to_video_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tokens, ld, video, (long)rows);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -21,12 +21,14 @@ BASE_MODELS = {  # generation/lvd.py:19-37
 }
 GUIDANCE_ATTN_KEYS = [("down", 1, 0, 0), ("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 2, 0)]  # lvd.py:66-73
 
-_components = dict(state_dict=None, unet_config=None, tokenizer=None, text_encoder=None, vae=None, device="cuda", img_dir="imgs")
+_components = dict(state_dict=None, unet_config=None, tokenizer=None, text_encoder=None, vae=None, vae_config=None, device="cuda", img_dir="imgs")
 
 
 def configure(**kw):
     """state_dict (reference-named UNet weights) / unet_config (ctor kwargs) / tokenizer / text_encoder / vae / device /
-    img_dir.  `state_dict="synthetic"` draws seeded random weights of the requested topology (plumbing and benchmarks)."""
+    img_dir.  `state_dict="synthetic"` draws seeded random weights of the requested topology (plumbing and benchmarks).
+    `vae` is a callable latents -> frames, an `AutoencoderKL.state_dict()` (decoded on the HIP kernels by
+    `lvd_amd.vae.HipVAEDecoder`, `vae_config` = VAEConfig kwargs) or "synthetic"."""
     unknown = set(kw) - set(_components)
     if unknown:
         raise TypeError(f"unknown components {sorted(unknown)}")
@@ -52,7 +54,17 @@ class Method:
             ucfg = UNetConfig(**{k: v for k, v in cfg_kw.items() if k in UNetConfig.__dataclass_fields__})
             sd = synthetic_state_dict(ucfg, seed=0, device=_components["device"])
         unet = UNet3DConditionModel.from_state_dict(sd, device=_components["device"], **cfg_kw)
-        self.pipe = TextToVideoSDPipeline(unet=unet, scheduler=DPMSolverPP2MSchedule(), vae=_components["vae"],
+        vae = _components["vae"]
+        if isinstance(vae, (dict, str)):
+            from ..vae import HipVAEDecoder
+            from ..weights import VAEConfig, synthetic_vae_state_dict
+            vcfg = VAEConfig(**(_components["vae_config"] or {}))
+            if isinstance(vae, str):
+                if vae != "synthetic":
+                    raise ValueError(f"vae={vae!r}: expected a callable, a state_dict or 'synthetic'")
+                vae = synthetic_vae_state_dict(vcfg, seed=0, device=_components["device"])
+            vae = HipVAEDecoder(vcfg, vae, device=_components["device"])
+        self.pipe = TextToVideoSDPipeline(unet=unet, scheduler=DPMSolverPP2MSchedule(), vae=vae,
                                           text_encoder=_components["text_encoder"], tokenizer=_components["tokenizer"]).to(_components["device"])
         self.pipe.guidance_models = None
         return self.base["H"], self.base["W"]

@@ -162,6 +162,8 @@ SYMBOLS = {
     "lvdhip_cfg_dpm_step": [C.c_void_p, C.c_void_p, f32, C.c_void_p, C.c_void_p, f32, f32, f32, f32, f32, C.c_int64, C.c_void_p],
     "lvdhip_axpy": [C.c_void_p, C.c_void_p, f32, C.c_int64, C.c_void_p],
     "lvdhip_reduce_sum": [C.c_void_p, C.c_int64, f32, C.c_void_p, C.c_void_p],
+    "lvdhip_softmax_rows": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
+    "lvdhip_tokens_to_video": [C.c_void_p, i32, C.c_void_p, C.c_int64, C.c_void_p],
 }
 
 _lib = None

@@ -409,3 +409,23 @@ def reduce_sum(x, scale=1.0, out=None):
         out = torch.empty((1,), dtype=torch.float32, device=x.device)
     hip.check(hip.lib().lvdhip_reduce_sum(_p(x), x.numel(), scale, _p(out), _stream()), "reduce_sum")
     return out
+
+
+def softmax_rows(x, out=None):
+    """Row softmax of an fp32 score matrix -> bf16 probabilities (VAE mid-block attention)."""
+    _chk_f32(x)
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    hip.check(hip.lib().lvdhip_softmax_rows(_p(x), _ld(x), _p(out), _ld(out), rows, cols, _stream()), "softmax_rows")
+    return out
+
+
+def tokens_to_video(tokens, frames, height, width):
+    """Decoded image tokens [(f,y,x), >=4] bf16 -> (frames, height, width, 3) fp32 in [0,1]."""
+    _chk_bf16(tokens)
+    rows = frames * height * width
+    assert tokens.shape[0] == rows
+    video = torch.empty((frames, height, width, 3), dtype=torch.float32, device=tokens.device)
+    hip.check(hip.lib().lvdhip_tokens_to_video(_p(tokens), _ld(tokens), _p(video), rows, _stream()), "tokens_to_video")
+    return video

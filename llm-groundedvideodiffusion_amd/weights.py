@@ -223,6 +223,78 @@ def synthetic_state_dict(cfg: UNetConfig, seed: int = 0, gain: float = 1.0, devi
     return sd
 
 
+# ----------------------------------------------------------------------------- VAE decoder
+@dataclass
+class VAEConfig:
+    """diffusers AutoencoderKL config of the zeroscope / modelscope checkpoints (SD VAE)."""
+    latent_channels: int = 4
+    out_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+VAE_TINY = dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)
+
+
+def vae_decoder_param_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
+    """`AutoencoderKL.state_dict()` names of the decode half (diffusers 0.27.2 Decoder / UNetMidBlock2D / UpDecoderBlock2D)."""
+    d = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        d[name + ".weight"] = (cout, cin, k, k)
+        d[name + ".bias"] = (cout,)
+
+    def res(name, cin, cout):
+        _norm(d, name + ".norm1", cin)
+        conv(name + ".conv1", cout, cin, 3)
+        _norm(d, name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cout, cin, 1)
+
+    top = cfg.block_out_channels[-1]
+    conv("decoder.conv_in", top, cfg.latent_channels, 3)
+    a = "decoder.mid_block.attentions.0"
+    _norm(d, a + ".group_norm", top)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        _lin(d, f"{a}.{nm}", top, top)
+    res("decoder.mid_block.resnets.0", top, top)
+    res("decoder.mid_block.resnets.1", top, top)
+    rev = list(reversed(cfg.block_out_channels))
+    cin = rev[0]
+    for i, cout in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+        cin = cout
+    _norm(d, "decoder.conv_norm_out", rev[-1])
+    conv("decoder.conv_out", cfg.out_channels, rev[-1], 3)
+    conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+    return d
+
+
+def synthetic_vae_state_dict(cfg: VAEConfig, seed: int = 0, gain: float = 1.0, device="cpu"):
+    """Seeded random decoder weights (bf16-representable), same recipe as `synthetic_state_dict`."""
+    sd = OrderedDict()
+    for name, shape in vae_decoder_param_shapes(cfg).items():
+        g = torch.Generator(device=device).manual_seed(_seed_for("vae." + name, seed))
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "weight" and len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif leaf == "bias":
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            t = gain * torch.randn(shape, generator=g, device=device) / math.sqrt(fan_in)
+        sd[name] = t.to(torch.bfloat16).to(torch.float32)
+    return sd
+
+
 # ----------------------------------------------------------------------------- packing helpers
 def pack_conv3x3(w):
     """[cout,cin,3,3] -> [cout, 9*cin] tap-major (k = (ky*3+kx)*cin + c)."""

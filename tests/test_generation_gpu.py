@@ -43,6 +43,24 @@ def test_lvd_run_writes_reference_file_contract(tmp_path):
     assert np.array_equal(again, frames) and not np.array_equal(other, frames)  # output is a function of the seed
 
 
+def test_lvd_run_with_hip_vae_decoder(tmp_path):
+    """Same run with the frames produced by the HIP VAE decoder (random-init decoder of a small AutoencoderKL topology)
+    instead of the injected stand-in: latents -> decode -> tensor2vid -> uint8 file contract, end to end on the GPU."""
+    cfg = UNetConfig(**SMALL)
+    _common.configure(state_dict=synthetic_state_dict(cfg, seed=0), unet_config=dict(SMALL), tokenizer=FakeClipTokenizer(),
+                      text_encoder=FakeTextEncoder(64), vae="synthetic", vae_config=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1),
+                      device="cuda", img_dir=str(tmp_path))
+    try:
+        assert lvd.init("modelscope256") == (256, 256)
+        demo = [c for c in CASES if c["cache"].startswith("cache_demo")][0]
+        layout = dsl.parse_layout_response(demo["prompt"], demo["response"])
+        frames = lvd.run(layout, seed=11, num_inference_steps=3, num_frames=16, repeat_ind=0, max_index_step=1, max_iter=1)
+        assert frames.dtype == np.uint8 and frames.shape == (16, 256, 256, 3)
+        assert 5 < frames.mean() < 250 and frames.std() > 1
+    finally:
+        _common.configure(vae=None, vae_config=None)
+
+
 @pytest.mark.parametrize("mod,name", [(lvd_gligen, "lvd-gligen"), (lvd_plus, "lvd-plus"), (zeroscope_dpm, "zeroscope")])
 def test_other_run_models(tmp_path, mod, name):
     _configure(tmp_path, gated=name != "zeroscope")
