@@ -204,6 +204,7 @@ typedef struct {
   int32_t kv_ninner, kv_os, kv_is, kv_step;   /* key/value row addressing (segment 1) */
   int32_t kv2_ninner, kv2_os, kv2_is, kv2_step;
   float scale;
+  int32_t causal;                       /* 1: key j > query i is masked (CLIP text encoder); forward only, one-wave kernel */
 } lvd_attn_params;
 int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream);
 
@@ -293,6 +294,8 @@ int lvdhip_upsample2x_bwd(const lvd_bf16* dy, lvd_bf16* dx, int32_t n, int32_t h
                           int32_t accumulate, void* stream);
 /* sinusoidal timestep embedding (diffusers Timesteps(flip_sin_to_cos=True, shift 0)) -> bf16 [n, dim] */
 int lvdhip_timestep_embedding(const float* t, lvd_bf16* out, int32_t n, int32_t dim, void* stream);
+/* gelu on a bf16 matrix: mode 0 = exact erf GELU, 1 = quick_gelu x*sigmoid(1.702x) (CLIP text MLP) */
+int lvdhip_gelu(const lvd_bf16* x, lvd_bf16* y, int64_t n, int32_t mode, void* stream);
 /* silu on a small bf16 matrix (temb) */
 int lvdhip_silu(const lvd_bf16* x, lvd_bf16* y, int64_t n, void* stream);
 /* CFG combine + DPM-Solver++(2M) update (models/controllable_pipeline_text_to_video_synth.py:926-950):

@@ -107,9 +107,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float v = st[e] * sc;
-      if (last) {
+      if (last || p.causal) {
         int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        v = (kidx < skv_tot) ? v : -1e30f;
+        v = (kidx < skv_tot && !(p.causal && kidx > qi)) ? v : -1e30f;
       }
       pv[e] = v;
       tmax = fmaxf(tmax, v);
@@ -344,7 +344,8 @@ extern "C" int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream) {
   LVD_CHECK(p->q_ninner > 0 && p->kv_ninner > 0, "attention_fwd: ninner must be > 0");
   static int force = -1;
   if (force < 0) { const char* e = getenv("LVD_ATTN_VARIANT"); force = e ? atoi(e) : 0; }
-  const bool use_v2 = force == 2 || (force == 0 && p->skv2 == 0 && p->sq >= 128 && p->skv >= 128);
+  LVD_CHECK(!p->causal || p->skv2 == 0, "attention_fwd: causal mask with a second KV segment is not defined");
+  const bool use_v2 = !p->causal && (force == 2 || (force == 0 && p->skv2 == 0 && p->sq >= 128 && p->skv >= 128));
   if (use_v2 && p->skv2 == 0) {
     dim3 grid(((p->sq + 127) / 128) * p->samples, p->heads);
     hipLaunchKernelGGL(attn_fwd_v2_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);

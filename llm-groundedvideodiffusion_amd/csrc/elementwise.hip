@@ -235,6 +235,14 @@ __global__ void tokens_to_video_kernel(const lvd_bf16* __restrict__ t, int ld, f
   }
 }
 
+// ---- GELU (CLIP text MLP): exact erf form or quick_gelu
+__global__ void gelu_kernel(const lvd_bf16* __restrict__ x, lvd_bf16* __restrict__ y, long n, int mode) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = bf2f(x[i]);
+    y[i] = f2bf(mode == 0 ? gelu_erf_f(v) : v / (1.f + __expf(-1.702f * v)));
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -300,6 +308,15 @@ extern "C" int lvdhip_timestep_embedding(const float* t, lvd_bf16* out, int32_t 
   LVD_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int lvdhip_gelu(const lvd_bf16* x, lvd_bf16* y, int64_t n, int32_t mode, void* stream) {
+  LVD_CHECK(x && y && n > 0 && (mode == 0 || mode == 1), "gelu: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, mode);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int lvdhip_silu(const lvd_bf16* x, lvd_bf16* y, int64_t n, void* stream) {
   LVD_CHECK(x && y, "silu: bad args");
   hipLaunchKernelGGL(silu_kernel, dim3(nblocks(n)), dim3(256), 0, ST, x, y, (long)n);

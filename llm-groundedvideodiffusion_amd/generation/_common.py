@@ -21,14 +21,16 @@ BASE_MODELS = {  # generation/lvd.py:19-37
 }
 GUIDANCE_ATTN_KEYS = [("down", 1, 0, 0), ("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 2, 0)]  # lvd.py:66-73
 
-_components = dict(state_dict=None, unet_config=None, tokenizer=None, text_encoder=None, vae=None, vae_config=None, device="cuda", img_dir="imgs")
+_components = dict(state_dict=None, unet_config=None, tokenizer=None, text_encoder=None, vae=None, vae_config=None, text_encoder_config=None, device="cuda", img_dir="imgs")
 
 
 def configure(**kw):
     """state_dict (reference-named UNet weights) / unet_config (ctor kwargs) / tokenizer / text_encoder / vae / device /
     img_dir.  `state_dict="synthetic"` draws seeded random weights of the requested topology (plumbing and benchmarks).
     `vae` is a callable latents -> frames, an `AutoencoderKL.state_dict()` (decoded on the HIP kernels by
-    `lvd_amd.vae.HipVAEDecoder`, `vae_config` = VAEConfig kwargs) or "synthetic"."""
+    `lvd_amd.vae.HipVAEDecoder`, `vae_config` = VAEConfig kwargs) or "synthetic".  `text_encoder` is a callable
+    input_ids -> (last_hidden_state, ...) or a `CLIPTextModel.state_dict()` (run by `lvd_amd.text_encoder.HipCLIPTextEncoder`,
+    `text_encoder_config` = CLIPTextConfig kwargs)."""
     unknown = set(kw) - set(_components)
     if unknown:
         raise TypeError(f"unknown components {sorted(unknown)}")
@@ -64,8 +66,12 @@ class Method:
                     raise ValueError(f"vae={vae!r}: expected a callable, a state_dict or 'synthetic'")
                 vae = synthetic_vae_state_dict(vcfg, seed=0, device=_components["device"])
             vae = HipVAEDecoder(vcfg, vae, device=_components["device"])
+        text_encoder = _components["text_encoder"]
+        if isinstance(text_encoder, dict):
+            from ..text_encoder import CLIPTextConfig, HipCLIPTextEncoder
+            text_encoder = HipCLIPTextEncoder(CLIPTextConfig(**(_components["text_encoder_config"] or {})), text_encoder, device=_components["device"])
         self.pipe = TextToVideoSDPipeline(unet=unet, scheduler=DPMSolverPP2MSchedule(), vae=vae,
-                                          text_encoder=_components["text_encoder"], tokenizer=_components["tokenizer"]).to(_components["device"])
+                                          text_encoder=text_encoder, tokenizer=_components["tokenizer"]).to(_components["device"])
         self.pipe.guidance_models = None
         return self.base["H"], self.base["W"]
 

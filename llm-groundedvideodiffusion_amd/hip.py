@@ -93,7 +93,7 @@ class AttnParams(C.Structure):
         ("q_ninner", i32), ("q_os", i32), ("q_is", i32), ("q_step", i32),
         ("kv_ninner", i32), ("kv_os", i32), ("kv_is", i32), ("kv_step", i32),
         ("kv2_ninner", i32), ("kv2_os", i32), ("kv2_is", i32), ("kv2_step", i32),
-        ("scale", f32),
+        ("scale", f32), ("causal", i32),
     ]
 
 
@@ -159,6 +159,7 @@ SYMBOLS = {
     "lvdhip_upsample2x_bwd": [C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p],
     "lvdhip_timestep_embedding": [C.c_void_p, C.c_void_p, i32, i32, C.c_void_p],
     "lvdhip_silu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "lvdhip_gelu": [C.c_void_p, C.c_void_p, C.c_int64, i32, C.c_void_p],
     "lvdhip_cfg_dpm_step": [C.c_void_p, C.c_void_p, f32, C.c_void_p, C.c_void_p, f32, f32, f32, f32, f32, C.c_int64, C.c_void_p],
     "lvdhip_axpy": [C.c_void_p, C.c_void_p, f32, C.c_int64, C.c_void_p],
     "lvdhip_reduce_sum": [C.c_void_p, C.c_int64, f32, C.c_void_p, C.c_void_p],

@@ -277,7 +277,7 @@ class RowMap:
 
 
 def attn_params(q, k, v, o, *, samples, heads, sq, skv, qmap: RowMap, kvmap: RowMap, scale, lse=None,
-                k2=None, v2=None, skv2=0, kv2map: Optional[RowMap] = None):
+                k2=None, v2=None, skv2=0, kv2map: Optional[RowMap] = None, causal=False):
     _chk_bf16(q, k, v, o, k2, v2)
     p = hip.AttnParams()
     p.q, p.ldq, p.k, p.ldk, p.v, p.ldv = _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v)
@@ -290,6 +290,7 @@ def attn_params(q, k, v, o, *, samples, heads, sq, skv, qmap: RowMap, kvmap: Row
     m2 = kv2map or RowMap()
     p.kv2_ninner, p.kv2_os, p.kv2_is, p.kv2_step = m2.ninner, m2.os, m2.is_, m2.step
     p.scale = scale
+    p.causal = int(causal)
     return p
 
 
@@ -429,3 +430,13 @@ def tokens_to_video(tokens, frames, height, width):
     video = torch.empty((frames, height, width, 3), dtype=torch.float32, device=tokens.device)
     hip.check(hip.lib().lvdhip_tokens_to_video(_p(tokens), _ld(tokens), _p(video), rows, _stream()), "tokens_to_video")
     return video
+
+
+def gelu(x, mode="gelu", out=None):
+    """Elementwise GELU on a bf16 matrix: "gelu" (exact erf) or "quick_gelu" (x * sigmoid(1.702 x))."""
+    _chk_bf16(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    hip.check(hip.lib().lvdhip_gelu(_p(x), _p(out), x.numel(), {"gelu": 0, "quick_gelu": 1}[mode], _stream()), "gelu")
+    return out
