@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
 //   V tile  transposed [64 d][32 key pairs (+2 pad)] written as packed key pairs, read as two ds_read_b64 per fragment
 constexpr int V2_VP = 34;
 
-__global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const lvd_attn_params p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_v2_kernel(const lvd_attn_params p) {
   __shared__ uint4 k_lds[2][64 * 8];
   __shared__ uint32_t vt_lds[2][64 * V2_VP];
 
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const lvd_attn_params 
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
     }
+    // softmax on the raw scores: the scale is folded into the exponent FMA (max over raw scores, scale > 0)
     float pv[2][16];
     float tmax = -1e30f;
     const bool last = kt + 1 == nt;
@@ -264,15 +265,15 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const lvd_attn_params 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float v = st[kb][e] * sc;
+        float v = st[kb][e];
         if (last) {
           int kidx = kt * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
           v = (kidx < skv) ? v : -1e30f;
+          st[kb][e] = v;
         }
-        pv[kb][e] = v;
         tmax = fmaxf(tmax, v);
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;
     if (__any(tmax > m + RESCALE_THR)) {
       float mn = fmaxf(m, tmax);
       float alpha = fast_exp2(m - mn);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(const lvd_attn_params 
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { pv[kb][e] = fast_exp2(pv[kb][e] - m); rs += pv[kb][e]; }
+      for (int e = 0; e < 16; ++e) { pv[kb][e] = fast_exp2(fmaf(st[kb][e], sc, -m)); rs += pv[kb][e]; }
     lsum += rs;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)

@@ -277,7 +277,7 @@ LVD_DEV bf16x8 frag_tr(const uint32_t* t, int d, int kd) {
   return as_bf16x8(make_uint4(lo.x, lo.y, h2.x, h2.y));
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_v2_kernel(const lvd_attn_bwd_params bp) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_v2_kernel(const lvd_attn_bwd_params bp) {
   __shared__ uint4 k_rm[2][64 * 8];
   __shared__ uint4 v_rm[2][64 * 8];
   __shared__ uint32_t k_tr[2][64 * VP2];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_v2_kernel(const lvd_attn_bwd_
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_v2_kernel(const lvd_attn_bwd_params bp) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_v2_kernel(const lvd_attn_bwd_params bp) {
   __shared__ uint4 q_rm[2][64 * 8];
   __shared__ uint4 do_rm[2][64 * 8];
   __shared__ uint32_t q_tr[2][64 * VP2];
