@@ -28,7 +28,7 @@ LVD_DEV long base_row(int s, int ninner, int os, int is) {
 constexpr float RESCALE_THR = 5.f;  // log2 units: deferred running-max update (see the softmax blocks)
 constexpr int VT_PITCH = 18;  // dwords per d-row of the transposed V tile (16 key pairs + 2 pad)
 
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const lvd_attn_params p) {
+__global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p) {
   __shared__ uint32_t vt[64 * VT_PITCH];
 
   const int lane = threadIdx.x;

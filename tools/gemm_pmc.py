@@ -5,6 +5,8 @@ import torch
 import lvd_amd
 from lvd_amd import ops
 dev = "cuda"
+if os.environ.get("LVD_GEMM_VARIANT"):
+    ops.set_gemm_autotune(False)  # pinned geometry: no tuning launches in the counter pass
 def rnd(*s): return torch.randn(*s, device=dev).bfloat16()
 B, F = 2, 24
 for (M, N, K, kind) in [(138240, 960, 320, "plain"), (138240, 320, 1280, "plain"), (34560, 640, 2560, "plain"), (138240, 320, 2880, "conv"), (34560, 640, 5760, "conv")]:
