@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   }
   // the ring is idle now: every wave transposes its accumulators through its own share of it
   constexpr int WAVE_DW = STAGES * TILE * 4 / NW;
-  static_assert(WAVE_DW >= 32 * (FN * 16 + 4), "ring too small for the epilogue strip");
+  static_assert(WAVE_DW >= 32 * (FN * 16 + 2), "ring too small for the epilogue strip");
   __builtin_amdgcn_s_barrier();  // all waves are done reading the last K tile (and every DMA has landed: vmcnt(0) above)
   ring_epilogue_auto<FM, FN>(p, acc, mbase, nbase, lane, reinterpret_cast<uint32_t*>(lds) + wave * WAVE_DW);
 }

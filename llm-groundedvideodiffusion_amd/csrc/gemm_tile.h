@@ -186,7 +186,8 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
 template <int FM, int FN, bool GEGLU>
 LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int lane, uint32_t* buf) {
   constexpr int W = GEGLU ? FN * 16 : FN * 32;  // output columns of this wave
-  constexpr int S = W / 2 + 4;                  // dwords per staged row (16-byte aligned rows, 2-way worst-case write conflict)
+  constexpr int S = W / 2 + 2;                  // dwords per staged row: S = 2 (mod 4) -> the 32 rows of a ds_write_b64 hit 32 distinct
+                                                // bank pairs (conflict-free); rows are 8-byte aligned, so the read side uses two b64
   constexpr int CPR = W / 8;                    // 16-byte chunks per row
   constexpr int PASSES = (32 * CPR + 63) / 64;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -264,7 +265,9 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
       const int mm = mbase + i * 32 + r;
       const int n = col0 + c * 8;
       if (idx < 32 * CPR && mm < p.M && n < ncols) {
-        uint4 v = *reinterpret_cast<const uint4*>(buf + r * S + c * 4);
+        const uint2 vlo = *reinterpret_cast<const uint2*>(buf + r * S + c * 4);
+        const uint2 vhi = *reinterpret_cast<const uint2*>(buf + r * S + c * 4 + 2);
+        uint4 v = make_uint4(vlo.x, vlo.y, vhi.x, vhi.y);
         lvd_bf16* o = out + (long)mm * p.ldc + n;
         if (p.res || p.accumulate) {
           float f[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
