@@ -244,18 +244,22 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
     // residual / accumulate operands first, all in flight together: the stores below may alias them as far as the
     // compiler knows, so a load inside the store loop would be chained behind the previous store
     uint2 rres[RP / 4], racc[RP / 4];
-    if (p.res || (p.accumulate && !p.out_fp32)) {
+    if (p.res) {  // clamped, never predicated per lane: a load in a lane branch is waited for at the end of that branch
 #pragma unroll
       for (int it = 0; it < RP / 4; ++it) {
         int idx = it * 64 + lane;
-        int row = idx >> 4, cq = idx & 15;
-        int m = mrow0 + row;
-        int n = nbase + cq * 4;
-        const bool ok = m < p.M && n < p.N;
-        rres[it] = make_uint2(0, 0);
-        racc[it] = make_uint2(0, 0);
-        if (ok && p.res) rres[it] = ldg8(p.res + (long)m * p.ldres + n);
-        if (ok && p.accumulate && !p.out_fp32) racc[it] = ldg8(reinterpret_cast<const lvd_bf16*>(p.out) + (long)m * p.ldc + n);
+        int m = min(mrow0 + (idx >> 4), p.M - 1);
+        int n = min(nbase + (idx & 15) * 4, p.N - 4);
+        rres[it] = ldg8(p.res + (long)m * p.ldres + n);
+      }
+    }
+    if (p.accumulate && !p.out_fp32) {
+#pragma unroll
+      for (int it = 0; it < RP / 4; ++it) {
+        int idx = it * 64 + lane;
+        int m = min(mrow0 + (idx >> 4), p.M - 1);
+        int n = min(nbase + (idx & 15) * 4, p.N - 4);
+        racc[it] = ldg8(reinterpret_cast<const lvd_bf16*>(p.out) + (long)m * p.ldc + n);
       }
     }
 #pragma unroll

@@ -105,13 +105,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     for (int idx = 0; idx < LPS; ++idx) stage_one(kt, slot, idx);
   };
 
+  // accumulators start from bias + temb row-bias (the K-split slices start from zero: their reduce kernel adds them)
   f32x16 acc[FM][FN];
+  if (SPLITK) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  } else {
+    ring_bias_init<FM, FN>(p, acc, p.m_begin + tm * BM + wm * FM * 32, tn * BN + wn * FN * 32, l31, hi);
+  }
 
   const int nk = (max(klim - kbeg, 0) + RBK - 1) / RBK;
   // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)

@@ -109,6 +109,29 @@ LVD_DEV RowInfo make_row(const lvd_gemm_params& p, int m, bool live) {
   return r;
 }
 
+// (Bias and temb row-bias are not applied by the epilogues below: the kernels start their accumulators from them, see
+// ring_bias_init — the loads then overlap the DMA prologue instead of sitting, one waited-for load per 4 columns, in the
+// epilogue, where they were the larger part of its time on the short-K layers.)
+template <int FM, int FN>
+LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], int mbase, int nbase, int l31, int hi) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = min(mbase + i * 32 + l31, p.M - 1);
+    const float* rb = p.rowbias ? p.rowbias + (long)(m / (p.rowbias ? p.rows_per_sample : 1)) * p.N : nullptr;
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = min(nbase + j * 32 + 8 * q + 4 * hi, p.N - 4);  // clamped: tail columns are never stored
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.rowbias) v += *reinterpret_cast<const f32x4*>(rb + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
+      }
+  }
+}
+
 // Epilogue straight from registers.  The MFMAs are issued as D = W_frag · X_frag^T, so lane (l31) owns token row m and
 // every 4 consecutive accumulator registers are 4 consecutive output channels: bias / temb row-bias / gate / residual /
 // GEGLU are applied on 8-byte row-contiguous vectors with no LDS round trip and no barrier.
@@ -129,10 +152,6 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
           f32x4 h, g;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
-          if (p.bias) {
-            h += *reinterpret_cast<const f32x4*>(p.bias + n);
-            g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-          }
           uint2 o;
           o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
           o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
@@ -140,7 +159,6 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
         }
       continue;
     }
-    const float* rb = p.rowbias ? p.rowbias + (long)(m / p.rows_per_sample) * p.N : nullptr;
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -150,8 +168,6 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
         v *= p.alpha;
         if (p.res) {
           uint2 r = ldg8(p.res + (long)m * p.ldres + n);
@@ -200,19 +216,28 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
     uint32_t* wrow = buf + l31 * S;
     // residual / accumulate operands of this 32-row block: all loads in flight before anything depends on them (the
     // stores below may alias them as far as the compiler knows, so it would otherwise chain load -> store -> load ...)
+    // Addresses are clamped instead of predicated: a load inside a per-lane branch makes the compiler wait for it at the end
+    // of that branch (vmcnt(0) after every load), which is exactly the serialisation this prefetch exists to avoid.
     uint4 rres[PASSES], racc[PASSES];
-    if (p.res || p.accumulate) {
+    static_assert((32 * CPR) % 64 == 0, "whole passes");
+    if (p.res) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
-        const int mm = mbase + i * 32 + r;
-        const int n = col0 + c * 8;
-        const bool ok = idx < 32 * CPR && mm < p.M && n < ncols;
-        rres[ps] = make_uint4(0, 0, 0, 0);
-        racc[ps] = make_uint4(0, 0, 0, 0);
-        if (ok && p.res) rres[ps] = ldg16(p.res + (long)mm * p.ldres + n);
-        if (ok && p.accumulate) racc[ps] = ldg16(out + (long)mm * p.ldc + n);
+        const int mm = min(mbase + i * 32 + r, p.M - 1);
+        const int n = min(col0 + c * 8, ncols - 8);
+        rres[ps] = ldg16(p.res + (long)mm * p.ldres + n);
+      }
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = ps * 64 + lane;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const int mm = min(mbase + i * 32 + r, p.M - 1);
+        const int n = min(col0 + c * 8, ncols - 8);
+        racc[ps] = ldg16(out + (long)mm * p.ldc + n);
       }
     }
     if (GEGLU) {
@@ -224,18 +249,12 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
           f32x4 h, g;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
-          if (p.bias && n + 32 < p.N) {
-            h += *reinterpret_cast<const f32x4*>(p.bias + n);
-            g += *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-          }
           uint2 o;
           o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
           o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
           *reinterpret_cast<uint2*>(wrow + b * 16 + 4 * q + 2 * hi) = o;
         }
     } else {
-      const int ms = m < p.M ? m : p.M - 1;
-      const float* rb = p.rowbias ? p.rowbias + (long)(ms / p.rows_per_sample) * p.N : nullptr;
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -244,10 +263,6 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-          if (n < p.N) {
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
-          }
           v *= p.alpha;
           uint2 o;
           o.x = pack2bf(v[0], v[1]);
@@ -264,7 +279,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
       const int r = idx / CPR, c = idx - r * CPR;
       const int mm = mbase + i * 32 + r;
       const int n = col0 + c * 8;
-      if (idx < 32 * CPR && mm < p.M && n < ncols) {
+      if (mm < p.M && n < ncols) {
         const uint2 vlo = *reinterpret_cast<const uint2*>(buf + r * S + c * 4);
         const uint2 vhi = *reinterpret_cast<const uint2*>(buf + r * S + c * 4 + 2);
         uint4 v = make_uint4(vlo.x, vlo.y, vhi.x, vhi.y);
