@@ -73,12 +73,23 @@ __global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool live = rl < RL;
   if (live) {
-#pragma unroll 4
-    for (int r = rbeg + rl; r < rend; r += RL) {
-      float v[8];
-      load8(p.x1, p.x2, p.ld1, p.ld2, p.c1, (long)s * rps + r, c, v);
+    // four rows per trip, row index clamped instead of predicated (a load inside a lane branch is waited for at the end of
+    // the branch, one memory round trip per row); the clamped duplicates are masked out of the sums
+    const bool first = c < p.c1;  // select the source pointer once: one load instruction, no branch around it
+    const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
+    const int ldx = first ? p.ld1 : p.ld2;
+    for (int r0 = rbeg + rl; r0 < rend; r0 += 4 * RL) {
+      uint4 raw[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+      for (int u = 0; u < 4; ++u) raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8(raw[u], v);
+        const float w = r0 + u * RL < rend ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += w * v[e]; s2[e] += w * v[e] * v[e]; }
+      }
     }
   }
   gn_fold_rows(red, s1, s2, VC, RL, vcid, rl, live, p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2);
@@ -134,9 +145,7 @@ __global__ void gn_apply_kernel(const lvd_gn_apply_params p, int VC, int RL, int
     uint4 raw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int r = r0 + u * RL;
-      raw[u] = make_uint4(0, 0, 0, 0);
-      if (r < rend) raw[u] = ldg16(xb + ((long)s * rps + r) * ldx);
+      raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);  // clamped, not predicated
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -179,19 +188,31 @@ __global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, i
       rstd[e] = p.mean_rstd[((long)s * p.groups + g) * 2 + 1];
       ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e];
     }
-#pragma unroll 2
-    for (int r = rbeg + rl; r < rend; r += RL) {
-      long row = (long)s * rps + r;
-      float v[8], dy[8];
-      load8(p.x1, p.x2, p.ld1, p.ld2, p.c1, row, c, v);
-      unpack8(ldg16(p.dy + row * p.lddy + c), dy);
+    const bool first = c < p.c1;
+    const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
+    const int ldx = first ? p.ld1 : p.ld2;
+    for (int r0 = rbeg + rl; r0 < rend; r0 += 2 * RL) {
+      uint4 rx[2], rdy[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float xh = (v[e] - mean[e]) * rstd[e];
-        float g = dy[e];
-        if (p.silu) g *= silu_grad_f(xh * ga[e] + be[e]);
-        g *= ga[e];
-        s1[e] += g; s2[e] += g * xh;
+      for (int u = 0; u < 2; ++u) {  // clamped rows, duplicates masked below
+        const long row = (long)s * rps + min(r0 + u * RL, rend - 1);
+        rx[u] = ldg16(xb + row * ldx);
+        rdy[u] = ldg16(p.dy + row * p.lddy + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float v[8], dy[8];
+        unpack8(rx[u], v);
+        unpack8(rdy[u], dy);
+        const float w = r0 + u * RL < rend ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = (v[e] - mean[e]) * rstd[e];
+          float g = dy[e];
+          if (p.silu) g *= silu_grad_f(xh * ga[e] + be[e]);
+          g *= ga[e] * w;
+          s1[e] += g; s2[e] += g * xh;
+        }
       }
     }
   }
@@ -238,14 +259,11 @@ __global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p, int VC, int
     uint4 rx[2], rdy[2], rac[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int r = r0 + u * RL;
-      rx[u] = make_uint4(0, 0, 0, 0); rdy[u] = rx[u]; rac[u] = rx[u];
-      if (r < rend) {
-        const long row = (long)s * rps + r;
-        rx[u] = ldg16(xb + row * ldx);
-        rdy[u] = ldg16(p.dy + row * p.lddy + c);
-        if (p.accumulate) rac[u] = ldg16(ob + row * ldo);
-      }
+      const long row = (long)s * rps + min(r0 + u * RL, rend - 1);  // clamped, not predicated
+      rx[u] = ldg16(xb + row * ldx);
+      rdy[u] = ldg16(p.dy + row * p.lddy + c);
+      rac[u] = make_uint4(0, 0, 0, 0);
+      if (p.accumulate) rac[u] = ldg16(ob + row * ldo);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
