@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
     // residual / accumulate operands first, all in flight together: the stores below may alias them as far as the
     // compiler knows, so a load inside the store loop would be chained behind the previous store
     uint2 rres[RP / 4], racc[RP / 4];
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};  // this lane's 4 columns are the same in every pass: one load, outside the lane branch
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + min(nbase + (lane & 15) * 4, p.N - 4));
     if (p.res) {  // clamped, never predicated per lane: a load in a lane branch is waited for at the end of that branch
 #pragma unroll
       for (int it = 0; it < RP / 4; ++it) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
       int n = nbase + cq * 4;
       if (m >= p.M || n >= p.N) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      v += bias4;
       if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
       v *= p.alpha;
       if (p.res) {
