@@ -105,7 +105,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     for (int idx = 0; idx < LPS; ++idx) stage_one(kt, slot, idx);
   };
 
-  // accumulators start from bias + temb row-bias (the K-split slices start from zero: their reduce kernel adds them)
+  const int nk = (max(klim - kbeg, 0) + RBK - 1) / RBK;
+  // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) stage(s, s);
+
+  // accumulators start from bias + temb row-bias (the K-split slices start from zero: their reduce kernel adds them); the
+  // loads are issued behind the DMA prologue so both latencies overlap
   f32x16 acc[FM][FN];
   if (SPLITK) {
 #pragma unroll
@@ -118,10 +124,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     ring_bias_init<FM, FN>(p, acc, p.m_begin + tm * BM + wm * FM * 32, tn * BN + wn * FN * 32, l31, hi);
   }
 
-  const int nk = (max(klim - kbeg, 0) + RBK - 1) / RBK;
-  // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) stage(s, s);
 
   if constexpr (PP) {
     // Ping-pong schedule for the 8-wave geometries (two waves per SIMD).  In the lock-step loop below both waves of a

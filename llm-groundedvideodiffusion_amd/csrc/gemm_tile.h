@@ -114,21 +114,42 @@ LVD_DEV RowInfo make_row(const lvd_gemm_params& p, int m, bool live) {
 // epilogue, where they were the larger part of its time on the short-K layers.)
 template <int FM, int FN>
 LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], int mbase, int nbase, int l31, int hi) {
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = min(mbase + i * 32 + l31, p.M - 1);
-    const float* rb = p.rowbias ? p.rowbias + (long)(m / (p.rowbias ? p.rows_per_sample : 1)) * p.N : nullptr;
+  // The uniform tests wrap whole load loops: a load alone in a conditional block is waited for at the end of that block,
+  // which would serialise the 20-40 loads of a wave (one L2 round trip each) in front of the first MFMA.
+  if (p.bias) {
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = min(nbase + j * 32 + 8 * q + 4 * hi, p.N - 4);  // clamped: tail columns are never stored
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.rowbias) v += *reinterpret_cast<const f32x4*>(rb + n);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
       }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+  if (p.rowbias) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = min(mbase + i * 32 + l31, p.M - 1);
+      const float* rb = p.rowbias + (long)(m / p.rows_per_sample) * p.N;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(rb + min(nbase + j * 32 + 8 * q + 4 * hi, p.N - 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+        }
+    }
   }
 }
 
