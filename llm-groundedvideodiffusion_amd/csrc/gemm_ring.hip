@@ -9,11 +9,18 @@
 //   * counted s_waitcnt vmcnt(N) + raw s_barrier: only the tile about to be consumed is waited for, the
 //     STAGES-2 younger tiles stay in flight across the barrier (hipcc's __syncthreads would drain them);
 //   * one barrier per K tile; the slot that was consumed in iteration k-1 is refilled right after the barrier.
+//   * what counted waits can and cannot do here: the compiler still puts vmcnt(0) in front of the first LDS read of an
+//     iteration (it cannot prove the in-flight DMA does not alias the stage being read), so in practice one tile of
+//     prefetch survives the barrier; issuing the DMA as inline asm removes that wait and changes nothing measurable —
+//     the L2->LDS path is throughput-bound at ~10-12 TB/s.
 // Geometry is a template: WMxWN waves, each owning an (FM*32)x(FN*32) accumulator tile.
-//   128x128 (2x2 waves, 2x2 frags)  — small/odd shapes, most workgroups per CU
-//   256x160 (4x1 waves, 2x5 frags)  — the model's channel counts are multiples of 160 (320·k): no wasted columns,
-//                                     0.7 LDS fragment reads per MFMA instead of 1.0
-//   256x128 (4x1 waves, 2x4 frags)  — GEGLU projections (hidden/gate pairs need an even fragment count)
+//   128x128 (2x2 waves, 2x2 frags)  — small/odd shapes, most workgroups per CU; also the K-split slices
+//   128x320 (2x2 waves, 2x5 frags)  — two workgroups per CU, N = 320·k exactly
+//   256x160 / 256x128 (4x1 waves)   — 0.7 LDS fragment reads per MFMA instead of 1.0
+//   256x320 / 256x256 (4x2 waves)   — 8 waves in two ping-pong groups, 142 / 128 flop per staged byte; 256x256 for GEGLU
+//                                     (hidden/gate pairs need an even fragment count) and N not a multiple of 320
+// Epilogue (gemm_tile.h): accumulators start from bias + temb row-bias; alpha / GEGLU in registers; a wave-private LDS
+// strip turns the lane-owns-a-row layout into full 128-byte lines; residual operands are prefetched per 32-row block.
 #include <cstdlib>
 #include "common.h"
 
