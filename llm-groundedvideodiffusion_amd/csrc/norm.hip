@@ -340,6 +340,76 @@ __global__ void ln_fwd_kernel(const lvd_ln_params p) {
   }
 }
 
+// LayerNorm forward for the model's channel counts (C = 40·LPR, LPR = 8 / 16 / 32 lanes per row: 320 / 640 / 1280): a wave
+// holds 64/LPR rows at once, every lane five 16-byte vectors of its row (consecutive lanes = consecutive 16 bytes: full
+// 128-byte lines), reductions are log2(LPR) shuffles, and gamma/beta stay in registers over LN_BATCH row batches.  The
+// one-wave-per-row kernel above keeps 40 of 64 lanes busy at C = 320, one load in flight per lane, and re-reads gamma /
+// beta (4x the bytes of the row itself) for every row.
+constexpr int LN_BATCH = 4;
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const lvd_ln_params p) {
+  constexpr int RPW = 64 / LPR;  // rows per wave per batch
+  const int lane = threadIdx.x & 63;
+  const int r = lane / LPR, c = lane % LPR;
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * LN_BATCH);
+  float ga[5][8], be[5][8];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int ch = (c + j * LPR) * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + ch + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.beta + ch + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ga[j][4 * q + e] = g[e]; be[j][4 * q + e] = b[e]; }
+    }
+  }
+  const float inv_c = 1.f / (float)p.c;
+#pragma unroll 1
+  for (int bt = 0; bt < LN_BATCH; ++bt) {
+    const long row = row0 + bt * RPW + r;
+    const long rowc = row < p.rows ? row : p.rows - 1;  // clamped, not predicated (the store is)
+    uint4 raw[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) raw[j] = ldg16(p.x + rowc * p.ldx + (c + j * LPR) * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float v[8];
+      unpack8(raw[j], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv_c;
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float v[8];
+      unpack8(raw[j], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q2 += d * d; }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+    const float rstd = rsqrtf(q2 * inv_c + p.eps);
+    if (row < p.rows) {
+      if (c == 0 && p.mean_rstd) { p.mean_rstd[row * 2] = mean; p.mean_rstd[row * 2 + 1] = rstd; }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float v[8];
+        unpack8(raw[j], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * ga[j][e] + be[j][e];
+        uint4 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+        stg16(p.y + row * p.ldy + (c + j * LPR) * 8, o);
+      }
+    }
+  }
+}
+
 __global__ void ln_bwd_kernel(const lvd_ln_bwd_params p) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -463,8 +533,19 @@ extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void
 extern "C" int lvdhip_layernorm(const lvd_ln_params* p, void* stream) {
   LVD_CHECK(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
   LVD_CHECK(p->c % 8 == 0 && p->c <= 512 * LN_MAXV, "layernorm: c=%d unsupported (need c%%8==0, c<=%d)", p->c, 512 * LN_MAXV);
+  hipStream_t s = (hipStream_t)stream;
+  const int lpr = p->c % 40 == 0 ? p->c / 40 : 0;
+  if (lpr == 8 || lpr == 16 || lpr == 32) {
+    const int rows_per_block = 4 * (64 / lpr) * LN_BATCH;
+    const dim3 grid((unsigned)((p->rows + rows_per_block - 1) / rows_per_block));
+    if (lpr == 8) hipLaunchKernelGGL(ln_fwd_rows_kernel<8>, grid, dim3(256), 0, s, *p);
+    else if (lpr == 16) hipLaunchKernelGGL(ln_fwd_rows_kernel<16>, grid, dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(ln_fwd_rows_kernel<32>, grid, dim3(256), 0, s, *p);
+    LVD_LAUNCH_CHECK();
+    return 0;
+  }
   int blocks = (p->rows + 3) / 4;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, s, *p);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -218,7 +218,7 @@ def test_groupnorm(C, rps, samples, two):
     close(got, gref, 1e-2, f"groupnorm bwd C={C}")
 
 
-@pytest.mark.parametrize("C", [64, 320, 1280])
+@pytest.mark.parametrize("C", [64, 320, 640, 1280, 1024])
 def test_layernorm(C):
     rows = 333
     x = bf(rnd(rows, C, seed=1) * 1.5 + 0.3)
