@@ -455,6 +455,76 @@ __global__ void ln_bwd_kernel(const lvd_ln_bwd_params p) {
   }
 }
 
+// backward counterpart of ln_fwd_rows_kernel (same row/lane mapping, gamma resident over the row batches)
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const lvd_ln_bwd_params p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int r = lane / LPR, c = lane % LPR;
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * LN_BATCH);
+  float ga[5][8];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + (c + j * LPR) * 8 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ga[j][4 * q + e] = g[e];
+    }
+  const float inv_c = 1.f / (float)p.c;
+#pragma unroll 1
+  for (int bt = 0; bt < LN_BATCH; ++bt) {
+    const long row = row0 + bt * RPW + r;
+    const long rowc = row < p.rows ? row : p.rows - 1;
+    uint4 rx[5], rd[5], ra[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      rx[j] = ldg16(p.x + rowc * p.ldx + (c + j * LPR) * 8);
+      rd[j] = ldg16(p.dy + rowc * p.lddy + (c + j * LPR) * 8);
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) ra[j] = ldg16(p.dx + rowc * p.lddx + (c + j * LPR) * 8);
+    }
+    const float2 mr = *reinterpret_cast<const float2*>(p.mean_rstd + rowc * 2);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float xv[8], dv[8];
+      unpack8(rx[j], xv);
+      unpack8(rd[j], dv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = dv[e] * ga[j][e];
+        a += g;
+        b += g * (xv[e] - mr.x) * mr.y;
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    const float m1 = a * inv_c, m2 = b * inv_c;
+    if (row < p.rows) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float xv[8], dv[8], dx[8];
+        unpack8(rx[j], xv);
+        unpack8(rd[j], dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dx[e] = mr.y * (dv[e] * ga[j][e] - m1 - (xv[e] - mr.x) * mr.y * m2);
+        if (p.accumulate) {
+          float q[8];
+          unpack8(ra[j], q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dx[e] += q[e];
+        }
+        uint4 w;
+        w.x = pack2bf(dx[0], dx[1]); w.y = pack2bf(dx[2], dx[3]); w.z = pack2bf(dx[4], dx[5]); w.w = pack2bf(dx[6], dx[7]);
+        stg16(p.dx + row * p.lddx + (c + j * LPR) * 8, w);
+      }
+    }
+  }
+}
+
 // row chunks per sample for the elementwise passes: ~8 workgroups per CU over the whole launch, >= 4 rows per row lane
 int gn_row_chunks(int samples, int rows_per_sample, int RL) {
   int want = (2048 + samples - 1) / samples;
@@ -553,8 +623,19 @@ extern "C" int lvdhip_layernorm(const lvd_ln_params* p, void* stream) {
 extern "C" int lvdhip_layernorm_bwd(const lvd_ln_bwd_params* p, void* stream) {
   LVD_CHECK(p && p->x && p->dy && p->dx && p->gamma && p->mean_rstd, "layernorm_bwd: null pointer");
   LVD_CHECK(p->c % 8 == 0 && p->c <= 512 * LN_MAXV, "layernorm_bwd: c=%d unsupported", p->c);
+  hipStream_t s = (hipStream_t)stream;
+  const int lpr = p->c % 40 == 0 ? p->c / 40 : 0;
+  if (lpr == 8 || lpr == 16 || lpr == 32) {
+    const int rows_per_block = 4 * (64 / lpr) * LN_BATCH;
+    const dim3 grid((unsigned)((p->rows + rows_per_block - 1) / rows_per_block));
+    if (lpr == 8) hipLaunchKernelGGL(ln_bwd_rows_kernel<8>, grid, dim3(256), 0, s, *p);
+    else if (lpr == 16) hipLaunchKernelGGL(ln_bwd_rows_kernel<16>, grid, dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(ln_bwd_rows_kernel<32>, grid, dim3(256), 0, s, *p);
+    LVD_LAUNCH_CHECK();
+    return 0;
+  }
   int blocks = (p->rows + 3) / 4;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, *p);
   LVD_LAUNCH_CHECK();
   return 0;
 }
