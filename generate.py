@@ -85,6 +85,9 @@ def main(argv=None):
         cache = dsl.LayoutCache(os.path.join(args.cache_dir, f"cache_{args.prompt_type}_{args.template_version}_{model}.json"))
     if args.prompt_type == "demo":
         prompts = PROMPTS_DEMO
+    elif args.prompt_type.startswith("lvd") and not args.prompts_file:
+        from lvd_amd.evaluation import get_prompts  # the 500-prompt benchmark (prompt.py:82-90); repeats walk the cache entries
+        prompts = get_prompts(args.prompt_type)
     elif args.prompts_file:
         prompts = [l.strip() for l in open(args.prompts_file) if l.strip()]
     else:
