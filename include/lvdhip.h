@@ -321,6 +321,28 @@ int lvdhip_softmax_rows(const float* x, int32_t ldx, lvd_bf16* y, int32_t ldy, i
 /* tokens [(f,y,x), ld>=4] bf16 (channels 0..2 = RGB in [-1,1]) -> video fp32 [(f,y,x), 3] = clamp(x/2+0.5, 0, 1) */
 int lvdhip_tokens_to_video(const lvd_bf16* tokens, int32_t ld, float* video, int64_t rows, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * OWL-ViT benchmark scoring (scripts/eval_owl_vit.py:70-96).  The ViT / text towers and the class /
+ * box heads run on the GEMM, LayerNorm, attention and GELU entry points above; these two are the ends of the detector.
+ * ------------------------------------------------------------------------------------------ */
+/* `processor(images=...)` (transformers 4.36.2 OwlViTImageProcessor): frames uint8 [B,H,W,3] -> PIL-exact bicubic resize to
+ * SxS (two 8-bit passes; xbounds/ybounds = (first tap, taps) per output coordinate, x/ycoef = [S, taps] coefficients with 22
+ * fractional bits, both computed by the caller), 1/255 rescale, (v-mean)/std, written as the patch matrix
+ * [B*(S/P)^2, ld >= 3*P*P] bf16 with columns (channel, y, x) = Conv2d weight order.  `resized` (uint8 [B,S,S,3]) is optional. */
+int lvdhip_frames_to_patches(const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t S, int32_t P,
+                             const int32_t* xbounds, const int32_t* xcoef, int32_t xtaps, const int32_t* ybounds,
+                             const int32_t* ycoef, int32_t ytaps, const float* mean3, const float* std3,
+                             lvd_bf16* patches, int32_t ld, uint8_t* resized, void* stream);
+/* OwlViTClassPredictionHead / box_predictor tails + `processor.post_process`: per image token r
+ *   logits[r,q] = (<e_r/(|e_r|+1e-6), queries_q> + shift_r) * (elu(scale_r)+1)   (finfo.min where query_mask[q]==0)
+ *   scores[r] = sigmoid(max_q logits), labels[r] = argmax_q, boxes[r] = corners(sigmoid(box_raw_r + box_bias[r % tokens]))
+ *   scaled by (img_w, img_h, img_w, img_h).  class_embeds fp32 [rows, ld>=D<=1024]; queries fp32 [Q,D] (already unit
+ *   length + eps as the head applies it); shift_scale fp32 [rows, ld>=2] = (shift, raw scale); host arrays mean3/std3. */
+int lvdhip_owl_detect_rows(const float* class_embeds, int32_t ld_embeds, int32_t D, const float* queries, int32_t Q,
+                           const int32_t* query_mask, const float* shift_scale, int32_t ld_shift_scale, const float* box_raw,
+                           int32_t ld_box, const float* box_bias, int32_t tokens_per_image, float img_w, float img_h,
+                           int64_t rows, float* logits, float* scores, int64_t* labels, float* boxes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

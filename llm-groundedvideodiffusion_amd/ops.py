@@ -440,3 +440,88 @@ def gelu(x, mode="gelu", out=None):
         out = torch.empty_like(x)
     hip.check(hip.lib().lvdhip_gelu(_p(x), _p(out), x.numel(), {"gelu": 0, "quick_gelu": 1}[mode], _stream()), "gelu")
     return out
+
+
+# ---- OWL-ViT scoring ends (detect.hip) ----------------------------------------------------------------------------------
+
+def _bicubic(x, a=-0.5):
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+_resample_tables = {}
+
+
+def pil_bicubic_table(in_size, out_size):
+    """Pillow's 8-bit resampling coefficients for one axis (Resample.c precompute_coeffs + normalize_coeffs_8bpc, bicubic
+    a = -0.5, support 2 widened by the downscale factor): bounds int32 [out, 2] = (first tap, taps), coef int32 [out, ksize]
+    with 22 fractional bits.  Evaluated in double precision in the library's operation order, so the integers are its own."""
+    key = (in_size, out_size)
+    if key not in _resample_tables:
+        import math
+        import numpy as np
+        scale = in_size / out_size
+        filterscale = max(scale, 1.0)
+        support = 2.0 * filterscale
+        ksize = int(math.ceil(support)) * 2 + 1
+        bounds = np.zeros((out_size, 2), dtype=np.int32)
+        coef = np.zeros((out_size, ksize), dtype=np.int32)
+        inv = 1.0 / filterscale
+        for o in range(out_size):
+            center = (o + 0.5) * scale
+            lo = max(int(center - support + 0.5), 0)
+            hi = min(int(center + support + 0.5), in_size)
+            w = [_bicubic((t + lo - center + 0.5) * inv) for t in range(hi - lo)]
+            total = 0.0
+            for v in w:
+                total += v
+            if total != 0.0:
+                w = [v / total for v in w]
+            bounds[o] = (lo, hi - lo)
+            coef[o, :hi - lo] = [int(v * (1 << 22) + (0.5 if v >= 0 else -0.5)) for v in w]
+        _resample_tables[key] = (bounds, coef)
+    return _resample_tables[key]
+
+
+def frames_to_patches(frames, size, patch, mean, std, return_resized=False):
+    """uint8 frames (B,H,W,3) on the GPU -> bf16 patch matrix [B*(size/patch)^2, 3*patch^2] (resize, rescale, normalise)."""
+    assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous() and frames.ndim == 4 and frames.shape[-1] == 3
+    B, H, W, _ = frames.shape
+    dev = frames.device
+    tabs = []
+    for n in (W, H):
+        key = (n, size, dev)
+        if key not in _resample_tables:
+            b, k = pil_bicubic_table(n, size)
+            _resample_tables[key] = (torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev))
+        tabs.append(_resample_tables[key])
+    (xb, xk), (yb, yk) = tabs
+    g = size // patch
+    patches = torch.empty((B * g * g, 3 * patch * patch), dtype=torch.bfloat16, device=dev)
+    resized = torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev) if return_resized else None
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    hip.check(hip.lib().lvdhip_frames_to_patches(_p(frames), B, H, W, size, patch, _p(xb), _p(xk), xk.shape[1], _p(yb), _p(yk), yk.shape[1],
+                                                 m3, s3, _p(patches), _ld(patches), _p(resized), _stream()), "frames_to_patches")
+    return (patches, resized) if return_resized else patches
+
+
+def owl_detect_rows(class_embeds, queries, shift_scale, box_raw, box_bias, tokens_per_image, img_w, img_h, query_mask=None):
+    """Fused tail of the OWL-ViT heads + post-process (see lvdhip_owl_detect_rows).  Returns (logits [rows,Q], scores [rows],
+    labels int64 [rows], boxes xyxy pixels [rows,4])."""
+    _chk_f32(class_embeds, queries, shift_scale, box_raw, box_bias)
+    rows, D = class_embeds.shape
+    Q = queries.shape[0]
+    assert queries.is_contiguous() and queries.shape[1] == D and box_bias.is_contiguous() and box_bias.shape == (tokens_per_image, 4)
+    dev = class_embeds.device
+    logits = torch.empty((rows, Q), dtype=torch.float32, device=dev)
+    scores = torch.empty((rows,), dtype=torch.float32, device=dev)
+    labels = torch.empty((rows,), dtype=torch.int64, device=dev)
+    boxes = torch.empty((rows, 4), dtype=torch.float32, device=dev)
+    hip.check(hip.lib().lvdhip_owl_detect_rows(_p(class_embeds), _ld(class_embeds), D, _p(queries), Q, _p(query_mask), _p(shift_scale), _ld(shift_scale),
+                                               _p(box_raw), _ld(box_raw), _p(box_bias), tokens_per_image, float(img_w), float(img_h), rows,
+                                               _p(logits), _p(scores), _p(labels), _p(boxes), _stream()), "owl_detect_rows")
+    return logits, scores, labels, boxes

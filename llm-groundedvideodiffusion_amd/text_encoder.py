@@ -38,6 +38,43 @@ class TextEncoderOutput(tuple):
     pooler_output = property(lambda self: self[1])
 
 
+def load_clip_layers(sd, prefix, n_layers, dev):
+    """Pre-LN CLIP encoder layers (text and vision towers share the block): fused q/k/v weight, bf16 matrices, fp32 vectors."""
+    bf = lambda t: t.to(dev, torch.bfloat16).contiguous()
+    f32 = lambda t: t.to(dev, torch.float32).contiguous()
+    layers = []
+    for i in range(n_layers):
+        p = f"{prefix}{i}."
+        qkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        qkv_b = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        layers.append(dict(
+            ln1=(f32(sd[p + "layer_norm1.weight"]), f32(sd[p + "layer_norm1.bias"])),
+            ln2=(f32(sd[p + "layer_norm2.weight"]), f32(sd[p + "layer_norm2.bias"])),
+            qkv=(bf(qkv), f32(qkv_b)),
+            out=(bf(sd[p + "self_attn.out_proj.weight"]), f32(sd[p + "self_attn.out_proj.bias"])),
+            fc1=(bf(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"])),
+            fc2=(bf(sd[p + "mlp.fc2.weight"]), f32(sd[p + "mlp.fc2.bias"]))))
+    return layers
+
+
+def run_clip_layers(x, layers, *, samples, seq, heads, causal, act, eps):
+    """x: bf16 [samples*seq, C] residual stream -> same, through every layer (LN, fused QKV GEMM, attention, out-proj with the
+    residual in the GEMM epilogue, LN, MLP)."""
+    C = x.shape[1]
+    rows = ops.RowMap(ninner=1, os=seq, is_=0, step=1)
+    for ly in layers:
+        h = ops.layernorm(x, *ly["ln1"], eps=eps)
+        qkv = ops.gemm(h, ly["qkv"][0], bias=ly["qkv"][1])
+        o = torch.empty((samples * seq, C), dtype=torch.bfloat16, device=x.device)
+        ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, samples=samples, heads=heads, sq=seq, skv=seq, qmap=rows, kvmap=rows,
+                          scale=64 ** -0.5, causal=causal)
+        x = ops.gemm(o, ly["out"][0], bias=ly["out"][1], res=x)
+        h = ops.layernorm(x, *ly["ln2"], eps=eps)
+        h = ops.gelu(ops.gemm(h, ly["fc1"][0], bias=ly["fc1"][1]), act)
+        x = ops.gemm(h, ly["fc2"][0], bias=ly["fc2"][1], res=x)
+    return x
+
+
 class HipCLIPTextEncoder:
     def __init__(self, cfg: CLIPTextConfig, state_dict, device="cuda"):
         assert cfg.hidden_size % cfg.num_attention_heads == 0 and cfg.hidden_size // cfg.num_attention_heads == 64, "head_dim must be 64"
@@ -48,18 +85,7 @@ class HipCLIPTextEncoder:
         f32 = lambda t: t.to(self.dev, torch.float32).contiguous()
         self.tok = f32(sd["embeddings.token_embedding.weight"])
         self.pos = f32(sd["embeddings.position_embedding.weight"])
-        self.layers = []
-        for i in range(cfg.num_hidden_layers):
-            p = f"encoder.layers.{i}."
-            qkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
-            qkv_b = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
-            self.layers.append(dict(
-                ln1=(f32(sd[p + "layer_norm1.weight"]), f32(sd[p + "layer_norm1.bias"])),
-                ln2=(f32(sd[p + "layer_norm2.weight"]), f32(sd[p + "layer_norm2.bias"])),
-                qkv=(bf(qkv), f32(qkv_b)),
-                out=(bf(sd[p + "self_attn.out_proj.weight"]), f32(sd[p + "self_attn.out_proj.bias"])),
-                fc1=(bf(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"])),
-                fc2=(bf(sd[p + "mlp.fc2.weight"]), f32(sd[p + "mlp.fc2.bias"]))))
+        self.layers = load_clip_layers(sd, "encoder.layers.", cfg.num_hidden_layers, self.dev)
         self.final_ln = (f32(sd["final_layer_norm.weight"]), f32(sd["final_layer_norm.bias"]))
 
     def __call__(self, input_ids, attention_mask=None, **_):
@@ -71,17 +97,7 @@ class HipCLIPTextEncoder:
         B, L = ids.shape
         C, H = cfg.hidden_size, cfg.num_attention_heads
         x = (self.tok[ids] + self.pos[:L][None]).reshape(B * L, C).to(torch.bfloat16).contiguous()
-        rows = ops.RowMap(ninner=1, os=L, is_=0, step=1)
-        for ly in self.layers:
-            h = ops.layernorm(x, *ly["ln1"], eps=cfg.layer_norm_eps)
-            qkv = ops.gemm(h, ly["qkv"][0], bias=ly["qkv"][1])
-            o = torch.empty((B * L, C), dtype=torch.bfloat16, device=self.dev)
-            ops.attention_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, samples=B, heads=H, sq=L, skv=L, qmap=rows, kvmap=rows,
-                              scale=64 ** -0.5, causal=True)
-            x = ops.gemm(o, ly["out"][0], bias=ly["out"][1], res=x)
-            h = ops.layernorm(x, *ly["ln2"], eps=cfg.layer_norm_eps)
-            h = ops.gelu(ops.gemm(h, ly["fc1"][0], bias=ly["fc1"][1]), cfg.hidden_act)
-            x = ops.gemm(h, ly["fc2"][0], bias=ly["fc2"][1], res=x)
+        x = run_clip_layers(x, self.layers, samples=B, seq=L, heads=H, causal=True, act=cfg.hidden_act, eps=cfg.layer_norm_eps)
         last = ops.layernorm(x, *self.final_ln, eps=cfg.layer_norm_eps).float().reshape(B, L, C)
         if cfg.eos_token_id == 2:  # transformers' legacy rule: EOS is the highest id of the CLIP vocabulary
             eos = ids.argmax(-1)
