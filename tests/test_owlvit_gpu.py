@@ -150,7 +150,7 @@ def _compare(cfg, frames, ids, seed):
     score_err = (out["scores"].cpu() - ref_scores).abs().max().item()
     # labels may differ only where the two best logits are closer than the bf16 noise
     top2 = rl.topk(min(2, rl.shape[-1]), -1).values
-    decided = (top2[..., 0] - top2[..., -1]) > 4 * (lg - rl).abs().max() if rl.shape[-1] > 1 else torch.ones_like(ref_labels, dtype=torch.bool)
+    decided = (top2[..., 0] - top2[..., -1]) > 2 * (lg - rl).abs().max(-1).values if rl.shape[-1] > 1 else torch.ones_like(ref_labels, dtype=torch.bool)
     label_ok = (out["labels"].cpu() == ref_labels)[decided].all().item()
     print(f"owlvit parity: logits rel-L2 {rel:.3e}, box err {box_err:.3e} of the frame, score err {score_err:.3e}, undecided labels {(~decided).sum().item()}")
     return rel, box_err, score_err, label_ok
@@ -160,7 +160,7 @@ def _compare(cfg, frames, ids, seed):
 def test_tiny_detector_matches_transformers():
     frames = random_frames(3, 96, 160, seed=1)
     rel, box_err, score_err, label_ok = _compare(TINY, frames, token_ids(TINY, 3, seed=2, pad_last=True), seed=3)
-    assert rel < 3e-2 and box_err < 1e-2 and score_err < 2e-2 and label_ok
+    assert rel < 2e-2 and box_err < 1e-2 and score_err < 1e-2 and label_ok  # measured 6.4e-3 / 2.3e-3 / 2.3e-3
 
 
 @pytest.mark.gpu
@@ -169,7 +169,7 @@ def test_base_patch32_topology_matches_transformers():
     cfg = OwlViTConfig()
     frames = random_frames(2, 320, 576, seed=4)
     rel, box_err, score_err, label_ok = _compare(cfg, frames, token_ids(cfg, 2, seed=5), seed=6)
-    assert rel < 4e-2 and box_err < 1e-2 and score_err < 3e-2 and label_ok
+    assert rel < 2e-2 and box_err < 1e-2 and score_err < 2e-2 and label_ok  # measured 6.8e-3 / 3.6e-3 / 5.8e-3
 
 
 @pytest.mark.gpu
