@@ -261,7 +261,8 @@ def main():
             "ms_per_step": round(ms_guided, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "lvd_zeroscope 576x320x24 (latent 40x72, 24 frames), guided step: 1 guidance iteration over 6 keys "
-                                   "+ CFG UNet forward (B=2) + DPM-Solver++ update; random-init zeroscope-topology weights (1411M params)",
+                                   "+ CFG UNet forward (B=2) + DPM-Solver++ update; random-init zeroscope-topology weights (1411M params)"
+                                   + (", gated topology (1624M params) with the GLIGEN fusers enabled" if args.gligen else ""),
                        "videos_per_gpu": 1, "parallelism": f"dp{world} (independent samples, no data-path collective)",
                        "guidance_scale": 9.0, "objects": 3},
             "unguided_ms_per_step": round(ms_unguided, 2),
