@@ -96,6 +96,9 @@ typedef struct {
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);
+/* Bytes of split-K workspace worth offering for this product (0 = none is ever used).  The caller allocates and owns it and
+ * may share one buffer among all launches of a stream; passing less (or NULL) is legal and disables the K-split plans. */
+int lvdhip_gemm_workspace_bytes(const lvd_gemm_params* p, int64_t* bytes);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+SiLU) over a token matrix.  A "sample" is rows_per_sample consecutive rows:

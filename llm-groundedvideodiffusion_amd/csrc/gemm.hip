@@ -416,3 +416,18 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   LVD_LAUNCH_CHECK();
   return 0;
 }
+
+// Workspace the split-K plans can use for this product (caller-owned, passed back in p->ws / p->ws_bytes).  Under-filled
+// grids (< 512 tiles of 128x128) may split the whole product into up to 16 fp32 slabs; larger products only ever split the
+// last partial round of wide tiles (run_with_tail), for which 64 MiB covers every plan.  A smaller or absent workspace is
+// legal: the launchers fall back to the unsplit geometry.
+extern "C" int lvdhip_gemm_workspace_bytes(const lvd_gemm_params* p, int64_t* bytes) {
+  LVD_CHECK(p && bytes && p->M > 0 && p->N > 0 && p->K > 0, "gemm_workspace_bytes: bad arguments");
+  if (p->act != LVD_ACT_NONE || p->K < 512) {
+    *bytes = 0;
+    return 0;
+  }
+  const long tiles = ((long)(p->M + 127) / 128) * ((p->N + 127) / 128);
+  *bytes = tiles < 512 ? 16L * p->M * p->N * 4 : 64L << 20;
+  return 0;
+}

@@ -143,11 +143,10 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     p.ldc = _ld(out)
     p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
     p.m_begin = m_begin
-    tiles = ((m + 127) // 128) * ((N + 127) // 128)
-    if act == ACT_NONE and K >= 512:
-        # split-K workspace: the whole product when the grid is under-filled, otherwise only the last partial round of
-        # tiles is ever split (gemm.hip run_with_tail): <= ~768 slabs of 128x128 fp32
-        ws = _splitk_workspace(a1.device, 16 * m * N * 4 if tiles < 512 else 64 << 20)
+    need = C.c_int64(0)
+    hip.check(hip.lib().lvdhip_gemm_workspace_bytes(C.byref(p), C.byref(need)), "gemm_workspace_bytes")
+    if need.value:
+        ws = _splitk_workspace(a1.device, need.value)  # one grow-only buffer per device, shared by all launches of the stream
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"] and not torch.cuda.is_current_stream_capturing():
         key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample) if conv is not None else None, int(out_fp32),

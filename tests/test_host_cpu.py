@@ -148,3 +148,15 @@ def _shard_worker(rank, world, q):
     assert [float(f[0, 0]) for f in allf] == [0.0, 1.0]
     q.put(jobs)
     dist.destroy_process_group()
+
+
+def test_gemm_workspace_query_needs_no_gpu():
+    """Pure host arithmetic of the C ABI: the split-K workspace the caller should offer (lvdhip_gemm_workspace_bytes)."""
+    p, n = hip.GemmParams(), ctypes.c_int64(-1)
+    for (m, nn, k, act), want in [((1080, 1280, 11520, 0), 16 * 1080 * 1280 * 4), ((138240, 1280, 11520, 0), 64 << 20), ((138240, 1280, 320, 0), 0),
+                                  ((1080, 2560, 1280, 1), 0)]:
+        p.M, p.N, p.K, p.act = m, nn, k, act
+        assert hip.lib().lvdhip_gemm_workspace_bytes(ctypes.byref(p), ctypes.byref(n)) == 0 and n.value == want
+    p.M = 0
+    assert hip.lib().lvdhip_gemm_workspace_bytes(ctypes.byref(p), ctypes.byref(n)) != 0
+    assert b"gemm_workspace_bytes" in hip.lib().lvdhip_last_error()
