@@ -192,3 +192,27 @@ def test_score_video_with_the_hip_detector():
     per_frame = det(video[:2], pairs[120][1].texts)
     boxes, scores, labels = per_frame[0]
     assert boxes.shape == (49, 4) and scores.shape == (49,) and set(np.unique(labels)) <= {0, 1} and np.isfinite(boxes).all()
+
+
+@pytest.mark.gpu
+def test_eval_owl_vit_cli(tmp_path):
+    """scripts/eval_owl_vit.py on a run directory laid out by generate.py ({run}/{prompt index}/video_0.joblib): full-size
+    detector topology with synthetic weights, two prompts, eval.json written in the reference's format."""
+    import importlib.util
+    import json
+    import os
+    import joblib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_owl_vit_cli", os.path.join(root, "scripts", "eval_owl_vit.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    for ind in (0, 100):
+        os.makedirs(tmp_path / str(ind))
+        joblib.dump(random_frames(24, 320, 576, seed=ind), tmp_path / str(ind) / "video_0.joblib")
+    os.makedirs(tmp_path / "1")
+    joblib.dump(random_frames(24, 64, 64, seed=1), tmp_path / "1" / "video_0.joblib")
+    joblib.dump(random_frames(24, 64, 64, seed=2), tmp_path / "1" / "video_1.joblib")  # ambiguous: skipped like the reference
+    board = cli.main(["--run_base_path", str(tmp_path), "--synthetic-weights", "--save-eval", "--detection_score_threshold", "0.3"])
+    assert board.total == {"numeracy": 1, "attribution": 1}
+    saved = json.load(open(tmp_path / "eval.json"))
+    assert saved["sample_counts_overall"] == 2 and set(saved["successes"]) == {"numeracy", "attribution"}
