@@ -197,7 +197,9 @@ class HipUNet3D:
             tape.push(bw)
         return out
 
-    def _conv3x3(self, x, name, g_in: Geom, *, tape, stride=1, upsample=0, res=None, rowbias=None, x2=None, out_fp32=False):
+    def _conv3x3(self, x, name, g_in: Geom, *, tape, stride=1, upsample=0, res=None, rowbias=None, x2=None, out_fp32=False, up_to=None):
+        if upsample and up_to is not None and tuple(up_to) != (2 * g_in.H, 2 * g_in.W):
+            return self._conv3x3_resized(x, name, g_in, up_to, tape=tape)
         W = self.w[name + ".weight"]
         hin, win = (g_in.H * 2, g_in.W * 2) if upsample else (g_in.H, g_in.W)
         hout, wout = ((hin - 1) // 2 + 1, (win - 1) // 2 + 1) if stride == 2 else (hin, win)
@@ -228,6 +230,30 @@ class HipUNet3D:
                     tape.accumulate(res, dy)
             tape.push(bw)
         return out, Geom(g_in.B, g_in.F, hout, wout)
+
+    def _conv3x3_resized(self, x, name, g_in: Geom, size, *, tape):
+        """Upsample2D with an explicit output size (latent H or W not divisible by 8: the reference passes the skip
+        connection's size as `upsample_size`, unet_3d_condition.py:711-730, and diffusers interpolates nearest to it).  Rare
+        and small (e.g. 256x144 -> latent 18x32 -> 9 -> 5 -> 3): the rows are gathered with the nearest index maps, then the
+        plain 3x3 conv kernel runs; the exact-x2 case stays fused in the conv loader."""
+        H2, W2 = size
+        n, C = g_in.B * g_in.F, x.shape[1]
+        idx = lambda src, dst: (torch.arange(dst, device=x.device, dtype=torch.float32) * (src / dst)).floor().long().clamp_(max=src - 1)
+        yi, xi = idx(g_in.H, H2), idx(g_in.W, W2)
+        big = x.view(n, g_in.H, g_in.W, C)[:, yi][:, :, xi].reshape(n * H2 * W2, C).contiguous()
+        geo = ops.ConvGeom(H2, W2, H2, W2, 1, 0)
+        out = ops.gemm(big, self.w[name + ".weight"], bias=self.w[name + ".bias"], mode=ops.A_CONV3X3, conv=geo)
+        if tape is not None:
+            def bw():
+                dy = tape.pop(out)
+                if dy is None:
+                    return
+                dbig = ops.gemm(dy, self.wt(name + ".weight", "conv"), mode=ops.A_CONV3X3, conv=geo).view(n, H2, W2, C).float()
+                d = torch.zeros((n, g_in.H, W2, C), dtype=torch.float32, device=x.device).index_add_(1, yi, dbig)
+                d = torch.zeros((n, g_in.H, g_in.W, C), dtype=torch.float32, device=x.device).index_add_(2, xi, d)
+                tape.accumulate(x, d.reshape(n * g_in.HW, C).to(torch.bfloat16))
+            tape.push(bw)
+        return out, Geom(g_in.B, g_in.F, H2, W2)
 
     def _tconv(self, x, name, g: Geom, *, tape, res=None):
         out = ops.gemm(x, self.w[name + ".weight"], bias=self.w[name + ".bias"], res=res, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
@@ -497,8 +523,7 @@ class HipUNet3D:
                     x = layer(f"up_blocks.{i}", j, ("up", i, j, 0), x, g, btype == "CrossAttnUpBlock3D", c, skip=skip)
                 if i != len(boc) - 1:
                     gt = skips[-1][1]
-                    assert (gt.H, gt.W) == (2 * g.H, 2 * g.W), "latent H,W must be divisible by 8 (nearest x2 upsampling only)"
-                    x, g = self._conv3x3(x, f"up_blocks.{i}.upsamplers.0.conv", g, tape=tape, upsample=1)
+                    x, g = self._conv3x3(x, f"up_blocks.{i}.upsamplers.0.conv", g, tape=tape, upsample=1, up_to=(gt.H, gt.W))
         except StopForward:
             self._tokens_in = tokens
             return None

@@ -56,3 +56,44 @@ def test_unet_odd_batch_and_frames_vs_oracle():
     e = rel(out, ref)
     print("2-layer unet rel-L2 vs oracle:", e)
     assert e < TOL
+
+
+def test_unet_latent_size_not_divisible_by_8_vs_oracle():
+    """BASELINE configs[0] territory (256x144 -> latent 18x32): the up path must resize to the skip connection's size
+    (18 -> 9 -> 5 -> 3 and back 3 -> 5 -> 9 -> 18), like the reference's `upsample_size` (unet_3d_condition.py:711-730)."""
+    from oracle import unet_ref
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=4)
+    gen = torch.Generator().manual_seed(6)
+    sample = torch.randn(2, 4, 3, 18, 20, generator=gen)
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, cfg, sample, 123, ehs)
+    out = HipUNet3D(cfg, sd).forward(sample.cuda(), 123, ehs.cuda())
+    e = rel(out, ref)
+    print("18x20 latent rel-L2 vs oracle:", e)
+    assert out.shape == ref.shape and e < TOL
+
+
+def test_resized_upsample_conv_backward_vs_autograd():
+    """Input gradient of the size-explicit Upsample2D (nearest to 5x9 from 3x5, then conv3x3) against torch autograd."""
+    import torch.nn.functional as F
+    from lvd_amd.engine import Geom, Tape
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=4)
+    net = HipUNet3D(cfg, sd)
+    name = "up_blocks.0.upsamplers.0.conv"
+    C = sd[name + ".weight"].shape[1]
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(2 * 3 * 5, C, generator=gen).bfloat16()
+    dy = torch.randn(2 * 5 * 9, sd[name + ".weight"].shape[0], generator=gen).bfloat16()
+    xr = x.float().reshape(2, 3, 5, C).permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(F.interpolate(xr, size=(5, 9), mode="nearest"), sd[name + ".weight"], sd[name + ".bias"], padding=1)
+    yr.backward(dy.float().reshape(2, 5, 9, -1).permute(0, 3, 1, 2))
+    tape = Tape()
+    xg = x.cuda()
+    out, g = net._conv3x3(xg, name, Geom(1, 2, 3, 5), tape=tape, upsample=1, up_to=(5, 9))
+    assert (g.H, g.W) == (5, 9) and rel(out, yr.detach().permute(0, 2, 3, 1).reshape(-1, out.shape[1])) < 1e-2
+    tape.accumulate(out, dy.cuda())
+    tape.backward()
+    assert rel(tape.pop(xg), xr.grad.permute(0, 2, 3, 1).reshape(-1, C)) < 1e-2

@@ -1,0 +1,70 @@
+"""The real zeroscope topology (1411 M parameters, block widths 320/640/1280/1280, concat widths up to 2560) against the
+fp32 oracle at sizes the host finishes in seconds: BASELINE configs[0] (256x144x8, latent 18x32 — not divisible by 8) for the
+CFG forward, and a 256x256x4 clip for one guidance iteration (hand-written backward vs autograd through the oracle).
+
+Measured (tools/full_topology_grad_probe.py, profiles/r01_full_topology_grad_probe.txt): loss equal to 1e-5 relative; latent update
+rel-L2 2.7-4.9 % per guidance key and 4.3 % over the six keys (cosine 0.999) — bf16 storage through the ~120-layer forward and
+backward of the two-layers-per-block topology (TINY, one layer per block: 2-3 %).  At a 128x128 clip the 4x4 maps of one key
+hold a near-tie in the top-k selection that flips between bf16 and fp32 (13 % on that key alone, every other key and the same
+key at 256x256 stay at 4 %): the energy is discontinuous in the selection set, which is why the test runs at 256x256."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import lvd_amd  # noqa: E402
+from lvd_amd import guidance  # noqa: E402
+from lvd_amd.engine import HipUNet3D  # noqa: E402
+from lvd_amd.weights import UNetConfig, synthetic_state_dict  # noqa: E402
+from oracle import guidance_ref, scheduler_ref, unet_ref  # noqa: E402
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def full():
+    cfg = UNetConfig()
+    sd = synthetic_state_dict(cfg, seed=0, device="cuda")
+    net = HipUNet3D(cfg, sd, device="cuda")
+    return cfg, net, {k: v.cpu() for k, v in sd.items()}  # fp32 host copy for the oracle (5.6 GB)
+
+
+def test_config0_cfg_forward_vs_oracle(full):
+    cfg, net, sd = full
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 18, 32, generator=gen)
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, cfg, x, 500, ehs)
+    out = net.forward(x.cuda(), 500, ehs.cuda())
+    e = rel(out, ref)
+    print("full topology, 256x144x8 CFG forward rel-L2 vs oracle:", e)
+    assert e < 3e-2
+
+
+def test_guidance_iteration_vs_oracle_autograd(full):
+    cfg, net, sd = full
+    gen = torch.Generator().manual_seed(1)
+    lat0 = torch.randn(1, 4, 4, 32, 32, generator=gen)
+    cond = torch.randn(1, 77, cfg.cross_attention_dim, generator=gen)
+    keys = [("down", 1, 0, 0), ("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 2, 0)]  # generation/lvd.py:66-73
+    boxes, pos = [[[0.1 + 0.1 * f, 0.2, 0.6 + 0.1 * f, 0.8] for f in range(4)], [[0.5, 0.5, 1.0, 1.0]] * 2 + [[0.0] * 4] * 2], [[2], [5, 6]]
+    hp = dict(loss_scale=5.0, loss_threshold=0.01, max_index_step=10, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0,
+              com_loss_scale=0.03, guidance_attn_keys=keys)
+    sched = scheduler_ref.DPMSolverPP2M()
+    t = 801
+
+    def unet_fn(x, tt, c, save, save_keys):
+        unet_ref.unet_forward(sd, cfg, x, int(tt), c, save_attn_to_dict=save, save_keys=save_keys, stop_after_key=keys[-1])
+
+    ref_lat, ref_loss = guidance_ref.latent_backward_guidance(unet_fn, sched.alphas_cumprod, cond, 0, boxes, pos, t, lat0.clone(), 10000.0,
+                                                              max_iter=1, base_attn_dim=(32, 32), **hp)
+    lat, loss = guidance.hip_latent_backward_guidance(sched, net, cond.cuda(), 0, boxes, pos, t, lat0.clone().cuda(), torch.tensor(10000.0),
+                                                      max_iter=1, **hp)
+    d, d_ref = lat.cpu() - lat0, ref_lat - lat0
+    print(f"full topology guidance: loss {float(loss):.4f} vs oracle {ref_loss:.4f}; update rel-L2 {rel(d, d_ref):.4f}")
+    assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
+    assert rel(d, d_ref) < 0.07  # measured 0.043
