@@ -132,12 +132,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local %= torch.cuda.device_count()  # one GPU per rank on a node; the modulo only matters for the single-GPU rehearsal below
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    backend = os.environ.get("LVD_BENCH_BACKEND", "nccl")  # "gloo": rehearse the N>1 control flow with all ranks on one GPU
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
 
     cfg = UNetConfig(attention_type="gated") if args.gligen else UNetConfig()
@@ -214,7 +219,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_guided = dt / args.steps * 1e3
