@@ -319,7 +319,7 @@ int lvdhip_reduce_sum(const float* x, int64_t n, float scale, float* out, void* 
  * two cover what is left: the single-head (dim 512) attention of the mid block computes its scores with lvdhip_gemm
  * (fp32 out) and normalises them here; the last one is VaeImageProcessor.postprocess.
  * ------------------------------------------------------------------------------------------ */
-/* y[r, :cols] = softmax(x[r, :cols]) ; fp32 in, bf16 out ; cols <= 4096 */
+/* y[r, :cols] = softmax(x[r, :cols]) ; fp32 in, bf16 out (rows wider than 4096 take a block-per-row kernel) */
 int lvdhip_softmax_rows(const float* x, int32_t ldx, lvd_bf16* y, int32_t ldy, int32_t rows, int32_t cols, void* stream);
 /* tokens [(f,y,x), ld>=4] bf16 (channels 0..2 = RGB in [-1,1]) -> video fp32 [(f,y,x), 3] = clamp(x/2+0.5, 0, 1) */
 int lvdhip_tokens_to_video(const lvd_bf16* tokens, int32_t ld, float* video, int64_t rows, void* stream);
@@ -328,11 +328,13 @@ int lvdhip_tokens_to_video(const lvd_bf16* tokens, int32_t ld, float* video, int
  * OWL-ViT benchmark scoring (scripts/eval_owl_vit.py:70-96).  The ViT / text towers and the class /
  * box heads run on the GEMM, LayerNorm, attention and GELU entry points above; these two are the ends of the detector.
  * ------------------------------------------------------------------------------------------ */
-/* `processor(images=...)` (transformers 4.36.2 OwlViTImageProcessor): frames uint8 [B,H,W,3] -> PIL-exact bicubic resize to
- * SxS (two 8-bit passes; xbounds/ybounds = (first tap, taps) per output coordinate, x/ycoef = [S, taps] coefficients with 22
- * fractional bits, both computed by the caller), 1/255 rescale, (v-mean)/std, written as the patch matrix
- * [B*(S/P)^2, ld >= 3*P*P] bf16 with columns (channel, y, x) = Conv2d weight order.  `resized` (uint8 [B,S,S,3]) is optional. */
-int lvdhip_frames_to_patches(const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t S, int32_t P,
+/* `processor(images=...)` (transformers 4.36.2 OwlViTImageProcessor) and `Image.resize` + `preprocess_video` of the upsampler
+ * (scripts/upsample.py:15-28): frames uint8 [B,H,W,3] -> PIL-exact resize to SH x SW (two 8-bit passes; xbounds/ybounds = (first
+ * tap, taps) per output coordinate, x/ycoef = [out, taps] coefficients with 22 fractional bits, computed by the caller for the
+ * filter it wants: bicubic, Lanczos), 1/255 rescale, (v-mean)/std, written as the patch matrix [B*(SH/P)*(SW/P), ld >= 3*P*P]
+ * bf16 with columns (channel, y, x) = Conv2d weight order (P = 1: a token matrix, columns >= 3 are left untouched).
+ * `resized` (uint8 [B,SH,SW,3]) is optional. */
+int lvdhip_frames_to_patches(const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t SH, int32_t SW, int32_t P,
                              const int32_t* xbounds, const int32_t* xcoef, int32_t xtaps, const int32_t* ybounds,
                              const int32_t* ycoef, int32_t ytaps, const float* mean3, const float* std3,
                              lvd_bf16* patches, int32_t ld, uint8_t* resized, void* stream);

@@ -16,15 +16,16 @@ LVD_DEV int clip8(int acc) {
 // One thread = one output pixel (3 channels).  Separable resampling with PIL's two-pass semantics: every tap row is first
 // resampled horizontally and rounded to 8 bits, then the column of those is resampled vertically and rounded again, with
 // the integer coefficient tables the host computed in double precision — bit-identical to Image.resize for uint8 RGB.
-__global__ void frames_to_patches_kernel(const uint8_t* __restrict__ frames, int B, int H, int W, int S, int P,
+// The filter (bicubic for the OWL-ViT processor, Lanczos for the upsampler's init video) lives entirely in the tables.
+__global__ void frames_to_patches_kernel(const uint8_t* __restrict__ frames, int B, int H, int W, int SH, int SW, int P,
                                          const int* __restrict__ xb, const int* __restrict__ xk, int xtaps,
                                          const int* __restrict__ yb, const int* __restrict__ yk, int ytaps,
                                          float m0, float m1, float m2, float s0, float s1, float s2,
                                          lvd_bf16* __restrict__ patches, int ld, uint8_t* __restrict__ resized) {
-  const long total = (long)B * S * S;
-  const int G = S / P;
+  const long total = (long)B * SH * SW;
+  const int GH = SH / P, GW = SW / P;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % S), oy = (int)((i / S) % S), b = (int)(i / ((long)S * S));
+    const int ox = (int)(i % SW), oy = (int)((i / SW) % SH), b = (int)(i / ((long)SH * SW));
     const int x0 = xb[2 * ox], xn = xb[2 * ox + 1], y0 = yb[2 * oy], yn = yb[2 * oy + 1];
     const int* kx = xk + (long)ox * xtaps;
     const int* ky = yk + (long)oy * ytaps;
@@ -49,7 +50,7 @@ __global__ void frames_to_patches_kernel(const uint8_t* __restrict__ frames, int
       r[0] = (uint8_t)v0, r[1] = (uint8_t)v1, r[2] = (uint8_t)v2;
     }
     // row = (frame, patch_y, patch_x), column = (channel, y in patch, x in patch): the flattening of Conv2d's [out, c, kh, kw]
-    lvd_bf16* dst = patches + ((long)(b * G + oy / P) * G + ox / P) * ld + (oy % P) * P + (ox % P);
+    lvd_bf16* dst = patches + ((long)(b * GH + oy / P) * GW + ox / P) * ld + (oy % P) * P + (ox % P);
     const float inv = 1.f / 255.f;
     dst[0] = f2bf((v0 * inv - m0) / s0);
     dst[P * P] = f2bf((v1 * inv - m1) / s1);
@@ -109,17 +110,17 @@ __global__ __launch_bounds__(256) void owl_detect_rows_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int lvdhip_frames_to_patches(const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t S, int32_t P,
+extern "C" int lvdhip_frames_to_patches(const uint8_t* frames, int32_t B, int32_t H, int32_t W, int32_t SH, int32_t SW, int32_t P,
                                         const int32_t* xbounds, const int32_t* xcoef, int32_t xtaps, const int32_t* ybounds,
                                         const int32_t* ycoef, int32_t ytaps, const float* mean3, const float* std3,
                                         lvd_bf16* patches, int32_t ld, uint8_t* resized, void* stream) {
   LVD_CHECK(frames && patches && xbounds && xcoef && ybounds && ycoef && mean3 && std3, "frames_to_patches: null argument");
-  LVD_CHECK(B > 0 && H > 0 && W > 0 && S > 0 && P > 0 && S % P == 0 && ld >= 3 * P * P && xtaps > 0 && ytaps > 0,
-            "frames_to_patches: bad geometry (B=%d H=%d W=%d S=%d P=%d ld=%d)", B, H, W, S, P, ld);
-  const long total = (long)B * S * S;
+  LVD_CHECK(B > 0 && H > 0 && W > 0 && SH > 0 && SW > 0 && P > 0 && SH % P == 0 && SW % P == 0 && ld >= 3 * P * P && xtaps > 0 && ytaps > 0,
+            "frames_to_patches: bad geometry (B=%d H=%d W=%d out=%dx%d P=%d ld=%d)", B, H, W, SH, SW, P, ld);
+  const long total = (long)B * SH * SW;
   long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(frames_to_patches_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames, B, H, W, S, P, xbounds, xcoef,
+  hipLaunchKernelGGL(frames_to_patches_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames, B, H, W, SH, SW, P, xbounds, xcoef,
                      xtaps, ybounds, ycoef, ytaps, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], patches, ld, resized);
   LVD_LAUNCH_CHECK();
   return 0;

@@ -223,6 +223,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// Rows wider than the register budget (the 72x128 = 9216-token mid attention of a 1024x576 decode / encode): one 256-thread
+// block per row, three passes over the row (it stays in L2: 37 KB), block reductions through LDS.
+__global__ __launch_bounds__(256) void softmax_rows_wide_kernel(const float* __restrict__ x, int ldx, lvd_bf16* __restrict__ y, int ldy, int cols) {
+  __shared__ float red[4];
+  const float* xr = x + (long)blockIdx.x * ldx;
+  lvd_bf16* yr = y + (long)blockIdx.x * ldy;
+  const int t = threadIdx.x;
+  float m = -3.0e38f;
+  for (int c = t; c < cols; c += 256) m = fmaxf(m, xr[c]);
+  m = wave_max(m);
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = t; c < cols; c += 256) s += fast_exp2((xr[c] - m) * 1.4426950408889634f);
+  s = wave_sum(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int c = t; c < cols; c += 256) yr[c] = f2bf(fast_exp2((xr[c] - m) * 1.4426950408889634f) * inv);
+}
+
 // ---- decoded image tokens [(f,y,x), >=3 channels] bf16 -> video float32 (f, y, x, 3) in [0,1]:  x/2 + 0.5 clamped
 // (VaeImageProcessor.postprocess + tensor2vid, controllable_pipeline_text_to_video_synth.py:66-88,374-400)
 __global__ void tokens_to_video_kernel(const lvd_bf16* __restrict__ t, int ld, float* __restrict__ video, long rows) {
@@ -346,8 +369,10 @@ extern "C" int lvdhip_reduce_sum(const float* x, int64_t n, float scale, float* 
 
 extern "C" int lvdhip_softmax_rows(const float* x, int32_t ldx, lvd_bf16* y, int32_t ldy, int32_t rows, int32_t cols, void* stream) {
   LVD_CHECK(x && y && rows > 0 && cols > 0, "softmax_rows: bad arguments");
-  LVD_CHECK(cols <= 64 * SM_MAXV, "softmax_rows: cols=%d > %d", cols, 64 * SM_MAXV);
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols);
+  if (cols <= 64 * SM_MAXV)
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols);
+  else
+    hipLaunchKernelGGL(softmax_rows_wide_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, cols);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -166,7 +166,7 @@ SYMBOLS = {
     "lvdhip_softmax_rows": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
     "lvdhip_gemm_workspace_bytes": [_P(GemmParams), C.POINTER(C.c_int64)],
     "lvdhip_tokens_to_video": [C.c_void_p, i32, C.c_void_p, C.c_int64, C.c_void_p],
-    "lvdhip_frames_to_patches": [C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p, C.c_void_p, i32, C.c_void_p, C.c_void_p, i32,
+    "lvdhip_frames_to_patches": [C.c_void_p, i32, i32, i32, i32, i32, i32, C.c_void_p, C.c_void_p, i32, C.c_void_p, C.c_void_p, i32,
                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, i32, C.c_void_p, C.c_void_p],
     "lvdhip_owl_detect_rows": [C.c_void_p, i32, i32, C.c_void_p, i32, C.c_void_p, C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, f32, f32,
                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -452,20 +452,29 @@ def _bicubic(x, a=-0.5):
     return 0.0
 
 
+def _lanczos(x):
+    import math
+    sinc = lambda v: 1.0 if v == 0.0 else math.sin(v * math.pi) / (v * math.pi)
+    return sinc(x) * sinc(x / 3) if -3.0 <= x < 3.0 else 0.0
+
+
+_FILTERS = {"bicubic": (_bicubic, 2.0), "lanczos": (_lanczos, 3.0)}
 _resample_tables = {}
 
 
-def pil_bicubic_table(in_size, out_size):
-    """Pillow's 8-bit resampling coefficients for one axis (Resample.c precompute_coeffs + normalize_coeffs_8bpc, bicubic
-    a = -0.5, support 2 widened by the downscale factor): bounds int32 [out, 2] = (first tap, taps), coef int32 [out, ksize]
-    with 22 fractional bits.  Evaluated in double precision in the library's operation order, so the integers are its own."""
-    key = (in_size, out_size)
+def pil_resample_table(in_size, out_size, kind="bicubic"):
+    """Pillow's 8-bit resampling coefficients for one axis (Resample.c precompute_coeffs + normalize_coeffs_8bpc; bicubic with
+    a = -0.5 / support 2, Lanczos with support 3, both widened by the downscale factor): bounds int32 [out, 2] = (first tap,
+    taps), coef int32 [out, ksize] with 22 fractional bits.  Evaluated in double precision in the library's operation order, so
+    the integers are its own."""
+    key = (in_size, out_size, kind)
     if key not in _resample_tables:
         import math
         import numpy as np
+        fn, base_support = _FILTERS[kind]
         scale = in_size / out_size
         filterscale = max(scale, 1.0)
-        support = 2.0 * filterscale
+        support = base_support * filterscale
         ksize = int(math.ceil(support)) * 2 + 1
         bounds = np.zeros((out_size, 2), dtype=np.int32)
         coef = np.zeros((out_size, ksize), dtype=np.int32)
@@ -474,7 +483,7 @@ def pil_bicubic_table(in_size, out_size):
             center = (o + 0.5) * scale
             lo = max(int(center - support + 0.5), 0)
             hi = min(int(center + support + 0.5), in_size)
-            w = [_bicubic((t + lo - center + 0.5) * inv) for t in range(hi - lo)]
+            w = [fn((t + lo - center + 0.5) * inv) for t in range(hi - lo)]
             total = 0.0
             for v in w:
                 total += v
@@ -486,24 +495,32 @@ def pil_bicubic_table(in_size, out_size):
     return _resample_tables[key]
 
 
-def frames_to_patches(frames, size, patch, mean, std, return_resized=False):
-    """uint8 frames (B,H,W,3) on the GPU -> bf16 patch matrix [B*(size/patch)^2, 3*patch^2] (resize, rescale, normalise)."""
+def pil_bicubic_table(in_size, out_size):
+    return pil_resample_table(in_size, out_size, "bicubic")
+
+
+def frames_to_patches(frames, size, patch, mean, std, return_resized=False, kind="bicubic", width=None):
+    """uint8 frames (B,H,W,3) on the GPU -> bf16 patch matrix [B*(SH/patch)*(SW/patch), width >= 3*patch^2] (PIL-exact resize to
+    `size` = S or (SH, SW), rescale, normalise).  Columns beyond 3*patch^2 (`width`, e.g. 8 for a conv_in token matrix) are zero."""
     assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous() and frames.ndim == 4 and frames.shape[-1] == 3
     B, H, W, _ = frames.shape
+    SH, SW = (size, size) if isinstance(size, int) else size
     dev = frames.device
     tabs = []
-    for n in (W, H):
-        key = (n, size, dev)
+    for n, s in ((W, SW), (H, SH)):
+        key = (n, s, kind, dev)
         if key not in _resample_tables:
-            b, k = pil_bicubic_table(n, size)
+            b, k = pil_resample_table(n, s, kind)
             _resample_tables[key] = (torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev))
         tabs.append(_resample_tables[key])
     (xb, xk), (yb, yk) = tabs
-    g = size // patch
-    patches = torch.empty((B * g * g, 3 * patch * patch), dtype=torch.bfloat16, device=dev)
-    resized = torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev) if return_resized else None
+    cols = 3 * patch * patch
+    width = cols if width is None else width
+    alloc = torch.empty if width == cols else torch.zeros
+    patches = alloc((B * (SH // patch) * (SW // patch), width), dtype=torch.bfloat16, device=dev)
+    resized = torch.empty((B, SH, SW, 3), dtype=torch.uint8, device=dev) if return_resized else None
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
-    hip.check(hip.lib().lvdhip_frames_to_patches(_p(frames), B, H, W, size, patch, _p(xb), _p(xk), xk.shape[1], _p(yb), _p(yk), yk.shape[1],
+    hip.check(hip.lib().lvdhip_frames_to_patches(_p(frames), B, H, W, SH, SW, patch, _p(xb), _p(xk), xk.shape[1], _p(yb), _p(yk), yk.shape[1],
                                                  m3, s3, _p(patches), _ld(patches), _p(resized), _stream()), "frames_to_patches")
     return (patches, resized) if return_resized else patches
 

@@ -276,10 +276,52 @@ def vae_decoder_param_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
     return d
 
 
-def synthetic_vae_state_dict(cfg: VAEConfig, seed: int = 0, gain: float = 1.0, device="cpu"):
-    """Seeded random decoder weights (bf16-representable), same recipe as `synthetic_state_dict`."""
+def vae_encoder_param_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
+    """`AutoencoderKL.state_dict()` names of the encode half (diffusers 0.27.2 Encoder / DownEncoderBlock2D / UNetMidBlock2D
+    + quant_conv): conv_in 3->c0, per level 2 resnets (+ stride-2 Downsample2D except at the last), mid block, 2*latent moments."""
+    d = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        d[name + ".weight"] = (cout, cin, k, k)
+        d[name + ".bias"] = (cout,)
+
+    def res(name, cin, cout):
+        _norm(d, name + ".norm1", cin)
+        conv(name + ".conv1", cout, cin, 3)
+        _norm(d, name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cout, cin, 1)
+
+    chans = cfg.block_out_channels
+    conv("encoder.conv_in", chans[0], cfg.out_channels, 3)
+    cin = chans[0]
+    for i, cout in enumerate(chans):
+        for j in range(cfg.layers_per_block):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != len(chans) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+        cin = cout
+    top = chans[-1]
+    a = "encoder.mid_block.attentions.0"
+    _norm(d, a + ".group_norm", top)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        _lin(d, f"{a}.{nm}", top, top)
+    res("encoder.mid_block.resnets.0", top, top)
+    res("encoder.mid_block.resnets.1", top, top)
+    _norm(d, "encoder.conv_norm_out", top)
+    conv("encoder.conv_out", 2 * cfg.latent_channels, top, 3)
+    conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return d
+
+
+def synthetic_vae_state_dict(cfg: VAEConfig, seed: int = 0, gain: float = 1.0, device="cpu", encoder=False):
+    """Seeded random decoder (and, with `encoder=True`, encoder) weights, bf16-representable, same recipe as `synthetic_state_dict`."""
     sd = OrderedDict()
-    for name, shape in vae_decoder_param_shapes(cfg).items():
+    shapes = vae_decoder_param_shapes(cfg)
+    if encoder:
+        shapes.update(vae_encoder_param_shapes(cfg))
+    for name, shape in shapes.items():
         g = torch.Generator(device=device).manual_seed(_seed_for("vae." + name, seed))
         leaf = name.rsplit(".", 1)[-1]
         if leaf == "weight" and len(shape) == 1:

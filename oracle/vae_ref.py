@@ -70,3 +70,33 @@ def decode_latents_to_video(sd, cfg, latents):
     img = decode(sd, cfg, z.float())
     img = (img / 2 + 0.5).clamp(0, 1)
     return img.reshape(b, f, 3, img.shape[-2], img.shape[-1]).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def encode_moments(sd, cfg, x):
+    """AutoencoderKL.encode(x).latent_dist parameters for x (N, 3, H, W) in [-1, 1] -> (mean, logvar), each (N, 4, H/8, W/8).
+    diffusers 0.27.2 Encoder: conv_in, DownEncoderBlock2D x4 (2 ResnetBlock2D each; Downsample2D(padding=0) = pad (0,1,0,1) then a
+    stride-2 3x3 conv, on all but the last), UNetMidBlock2D, GroupNorm + SiLU + conv_out to 2*latent channels, quant_conv (1x1);
+    DiagonalGaussianDistribution clamps logvar to [-30, 20].  PARITY UNPINNED like the decoder."""
+    x = _conv(sd, "encoder.conv_in", x, 1)
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            x = resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", x)
+        if i != nb - 1:
+            n = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[n + ".weight"], sd[n + ".bias"], stride=2)
+    x = resnet(sd, "encoder.mid_block.resnets.0", x)
+    x = mid_attention(sd, "encoder.mid_block.attentions.0", x)
+    x = resnet(sd, "encoder.mid_block.resnets.1", x)
+    x = _conv(sd, "encoder.conv_out", F.silu(_gn(sd, "encoder.conv_norm_out", x)), 1)
+    mean, logvar = _conv(sd, "quant_conv", x, 0).chunk(2, dim=1)
+    return mean, logvar.clamp(-30.0, 20.0)
+
+
+def encode_video(sd, cfg, frames_uint8, eps):
+    """VideoToVideoSDPipeline.prepare_latents up to the noise: frames (F, H, W, 3) uint8 -> 2*(v/255)-1 -> latent_dist.sample
+    with the given standard-normal `eps` (F, 4, h, w) -> scaling_factor * z as (1, 4, F, h, w)."""
+    x = (2.0 * (torch.as_tensor(frames_uint8).float() / 255.0) - 1.0).permute(0, 3, 1, 2)
+    mean, logvar = encode_moments(sd, cfg, x)
+    z = mean + torch.exp(0.5 * logvar) * eps
+    return (cfg.scaling_factor * z).permute(1, 0, 2, 3).unsqueeze(0)
