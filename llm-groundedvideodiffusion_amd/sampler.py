@@ -68,6 +68,11 @@ class DPMSolverPP2MSchedule:
         k = 0.5 * a_t * e / r0
         return a_s, s_s, c_x, -a_t * e - k, k
 
+    def add_noise(self, x, noise, i):
+        """DPMSolverMultistepScheduler.add_noise at schedule position i: alpha_i x + sigma_i noise (video-to-video start)."""
+        a, s = self._alpha_sigma(float(self.sigmas[i]))
+        return a * x + s * noise
+
     def advance(self):
         self.lower_order_nums = min(self.lower_order_nums + 1, 2)
         self.step_index += 1

@@ -67,3 +67,8 @@ class DPMSolverPP2M:
         self.lower_order_nums = min(self.lower_order_nums + 1, 2)
         self.step_index += 1
         return out
+
+    def add_noise(self, x, noise, i):
+        """alpha_i x + sigma_i noise at schedule position i (DPMSolverMultistepScheduler.add_noise looks the sigma up by timestep)."""
+        a, s = self._alpha_sigma(float(self.sigmas[i]))
+        return a * x + s * noise
