@@ -27,13 +27,16 @@ def test_get_timesteps_rule():
     assert HipVideoToVideo.get_timesteps(50, 0.0) == 50 and HipVideoToVideo.get_timesteps(4, 0.5) == 2
 
 
-def test_video_to_video_vs_oracle_loop():
+@pytest.mark.parametrize("scale,tol_lat,tol_img", [(1.0, 5e-2, 0.02), (15.0, 0.2, 0.04)])
+def test_video_to_video_vs_oracle_loop(scale, tol_lat, tol_img):
+    """scale 1 pins the loop itself (timesteps, add_noise, draw order, solver, decode) at the bf16 noise floor; scale 15 is the
+    pipeline default: CFG multiplies the bf16 noise of (eps_c - eps_u) by 15 (measured 0.097 on the latents)."""
     from PIL import Image
     ucfg, vcfg = UNetConfig(**TINY), VAEConfig(**VAE_TINY)
     usd, vsd = synthetic_state_dict(ucfg, seed=0), synthetic_vae_state_dict(vcfg, seed=1, encoder=True)
     rng = np.random.RandomState(0)
     video = (np.kron(rng.randint(0, 256, (4, 4, 4, 3)), np.ones((1, 8, 8, 1))) * 0.7 + rng.randint(0, 77, (4, 32, 32, 3))).astype(np.uint8)
-    size, steps, strength, scale = (64, 64), 4, 0.5, 15.0
+    size, steps, strength = (64, 64), 4, 0.5
     gen = torch.Generator().manual_seed(3)
     pe, ne = torch.randn(1, 77, ucfg.cross_attention_dim, generator=gen), torch.randn(1, 77, ucfg.cross_attention_dim, generator=gen)
 
@@ -60,10 +63,9 @@ def test_video_to_video_vs_oracle_loop():
             x = sch.step(e[0:1] + scale * (e[1:2] - e[0:1]), x)
     ref_frames = vae_ref.decode_latents_to_video(vsd, vcfg, x)[0]
     e_lat, e_img = rel(lat, x), (frames.cpu() - ref_frames).abs().mean().item()
-    print(f"video-to-video: latents rel-L2 {e_lat:.4f} vs oracle loop, frames mean abs diff {e_img:.4f}")
+    print(f"video-to-video (CFG scale {scale}): latents rel-L2 {e_lat:.4f} vs oracle loop, frames mean abs diff {e_img:.4f}")
     assert frames.shape == (4, 64, 64, 3) and float(frames.min()) >= 0 and float(frames.max()) <= 1
-    # CFG scale 15 multiplies the bf16 noise of (eps_c - eps_u); two solver steps and the decoder follow
-    assert e_lat < 0.1 and e_img < 0.03
+    assert e_lat < tol_lat and e_img < tol_img
 
 
 def test_upsample_cli_smoke(tmp_path):
