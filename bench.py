@@ -246,7 +246,10 @@ def main():
         n, secs, fl = agg[dom]
         ach = fl / secs / 1e12
         roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n, "sampled_every": gt.stride,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "traffic_note": "not collected live (needs rocprofv3 --pmc); per-shape FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/r01_gemm_pmc_traffic.txt "
+                                "(e.g. M=138240 N=960 K=320: 113 MB fetched vs 89 MB algorithmic, 240 MB written vs 265 MB)",
+                "launches": n, "sampled_every": gt.stride,
                 "class_launches_in_timed_region": gt.count, "avg_launch_us": round(secs / n * 1e6, 1),
                 "flops_per_launch": round(fl / n / 1e9, 2), "flops_per_launch_unit": "GFLOP",
                 "all_gemm": {names[m]: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 * gt.stride / args.steps, 2), "tflops": round(v[2] / v[1] / 1e12, 1)} for m, v in agg.items()}}
