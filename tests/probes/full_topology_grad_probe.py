@@ -6,12 +6,12 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lvd_amd  # noqa: E402,F401
 from lvd_amd import guidance  # noqa: E402
 from lvd_amd.engine import HipUNet3D  # noqa: E402
 from lvd_amd.weights import UNetConfig, synthetic_state_dict  # noqa: E402
-from oracle import guidance_ref, scheduler_ref, unet_ref  # noqa: E402  (diagnostic tool: the oracle is the checker)
+from oracle import guidance_ref, scheduler_ref, unet_ref  # noqa: E402  (test-side diagnostic: lives under tests/ because only tests may use the oracle)
 
 rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
 cfg = UNetConfig()

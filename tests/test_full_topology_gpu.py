@@ -2,7 +2,7 @@
 fp32 oracle at sizes the host finishes in seconds: BASELINE configs[0] (256x144x8, latent 18x32 — not divisible by 8) for the
 CFG forward, and a 256x256x4 clip for one guidance iteration (hand-written backward vs autograd through the oracle).
 
-Measured (tools/full_topology_grad_probe.py, profiles/r01_full_topology_grad_probe.txt): loss equal to 1e-5 relative; latent update
+Measured (tests/probes/full_topology_grad_probe.py, profiles/r01_full_topology_grad_probe.txt): loss equal to 1e-5 relative; latent update
 rel-L2 2.7-4.9 % per guidance key and 4.3 % over the six keys (cosine 0.999) — bf16 storage through the ~120-layer forward and
 backward of the two-layers-per-block topology (TINY, one layer per block: 2-3 %).  At a 128x128 clip the 4x4 maps of one key
 hold a near-tie in the top-k selection that flips between bf16 and fp32 (13 % on that key alone, every other key and the same
