@@ -125,3 +125,26 @@ def test_scoreboard_json(tmp_path):
     d = json.load(open(tmp_path / "eval.json"))
     assert d["success_counts"] == {"numeracy": 1, "sequential": 1} and d["sample_counts_overall"] == 3
     assert d["successes"]["numeracy"] == [True, False]
+
+
+def test_generate_cli_walks_the_benchmark_prompts(tmp_path, monkeypatch, capsys):
+    """`generate.py --prompt-type lvd --dry-run`: the 500 benchmark prompts in order, every one served by the shipped GPT-4
+    cache (repeated prompts consume successive cached responses), 250 per rank when sharded over two ranks."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("generate_cli", os.path.join(root, "generate.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    name = "cache_lvd_v0.1_gpt-4-1106-preview.json"
+    with gzip.open(os.path.join(GOLD, name + ".gz"), "rb") as f:
+        (tmp_path / name).write_bytes(f.read())
+    base = ["--model", "gpt-4", "--template_version", "v0.1", "--prompt-type", "lvd", "--run-model", "lvd_zeroscope", "--dry-run",
+            "--cache-dir", str(tmp_path), "--img-root", str(tmp_path / "img")]
+    gen.main(base)
+    out = capsys.readouterr().out
+    assert out.count("parsed_layout:") == 500 and "Cache miss" not in out
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    gen.main(base + ["--force_run_ind", "7"])
+    out = capsys.readouterr().out
+    assert out.count("parsed_layout:") == 250 and "run7" in out
