@@ -158,6 +158,14 @@ typedef struct {
 } lvd_gn_bwd_apply_params;
 int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream);
 
+/* Single-launch variants for small samples (deep UNet levels: a tensor is a few MB and the three launches above cost three
+ * launch floors): one workgroup per (sample, group) computes the statistics and applies them; the second pass over its slab
+ * (rows_per_sample x c/groups elements, meant for <= 128 KB) hits L2.  Same results as stats+apply up to fp32 summation order.
+ * `s->partial`, `s->chunks`, `s->scale_shift` and `p->gsum` are not used (may be NULL); `s->mean_rstd` is still written for the
+ * backward.  Needs an even number of channels per group. */
+int lvdhip_groupnorm_fused(const lvd_gn_stats_params* s, const lvd_gn_apply_params* a, void* stream);
+int lvdhip_groupnorm_bwd_fused(const lvd_gn_bwd_apply_params* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over channels (BasicTransformerBlock.norm1/2/3, GatedSelfAttentionDense.norm1/2
  *   models/attention.py:113,140,153,36-37), eps 1e-5, affine.  Saves (mean, rstd) per row.

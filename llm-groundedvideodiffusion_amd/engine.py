@@ -272,8 +272,7 @@ class HipUNet3D:
     def _groupnorm(self, x, name, rps, *, tape, eps, silu, x2=None):
         gamma, beta = self.w[name + ".weight"], self.w[name + ".bias"]
         G = self.cfg.norm_num_groups
-        ss, mr = ops.groupnorm_stats(x, gamma, beta, rps, groups=G, eps=eps, x2=x2)
-        out = ops.groupnorm_apply(x, ss, rps, silu=silu, x2=x2)
+        out, mr = ops.groupnorm_auto(x, gamma, beta, rps, groups=G, eps=eps, silu=silu, x2=x2)
         if tape is not None:
             def bw():
                 dy = tape.pop(out)

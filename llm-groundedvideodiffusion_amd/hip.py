@@ -143,6 +143,8 @@ SYMBOLS = {
     "lvdhip_groupnorm_apply": [_P(GnApplyParams), C.c_void_p],
     "lvdhip_groupnorm_bwd_stats": [_P(GnBwdStatsParams), C.c_void_p],
     "lvdhip_groupnorm_bwd_apply": [_P(GnBwdApplyParams), C.c_void_p],
+    "lvdhip_groupnorm_fused": [_P(GnStatsParams), _P(GnApplyParams), C.c_void_p],
+    "lvdhip_groupnorm_bwd_fused": [_P(GnBwdApplyParams), C.c_void_p],
     "lvdhip_layernorm": [_P(LnParams), C.c_void_p],
     "lvdhip_layernorm_bwd": [_P(LnBwdParams), C.c_void_p],
     "lvdhip_attention_fwd": [_P(AttnParams), C.c_void_p],

@@ -5,6 +5,7 @@ PyTorch is used only as the device-memory container and stream provider: every f
 hand-written HIP kernels on torch's current stream.  Nothing in this file computes with torch ops.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -198,9 +199,46 @@ def groupnorm_apply(x1, scale_shift, rows_per_sample, *, silu=False, x2=None, ou
     return out
 
 
-def groupnorm(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None, return_stats=False):
+# Small samples take the single-launch kernels (norm_small.hip): a (sample, group) slab of at most 64 Ki elements (128 KB: its
+# second pass is an L2 hit) and a tensor small enough that the three launches of the two-stage path are launch-bound.
+_gn_fused = {"max_slab": 65536, "max_bytes": int(os.environ.get("LVD_GN_FUSED_MAX_MB", "24")) << 20}
+
+
+def groupnorm_fused_ok(rows, c, rows_per_sample, groups):
+    cpg = c // groups
+    return cpg % 2 == 0 and rows_per_sample * cpg <= _gn_fused["max_slab"] and rows * c * 2 <= _gn_fused["max_bytes"]
+
+
+def groupnorm_fused(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None):
+    """GroupNorm(+SiLU) in one launch (small samples).  Returns (y, mean_rstd [S,G,2])."""
+    _chk_bf16(x1, x2)
+    _chk_f32(gamma, beta)
+    rows, c1 = x1.shape
+    c = c1 + (x2.shape[1] if x2 is not None else 0)
+    if out is None:
+        out = torch.empty((rows, c), dtype=torch.bfloat16, device=x1.device)
+    mr = torch.empty((rows // rows_per_sample, groups, 2), dtype=torch.float32, device=x1.device)
+    s, a = hip.GnStatsParams(), hip.GnApplyParams()
+    for q in (s, a):
+        q.x1, q.x2, q.ld1, q.ld2, q.c1, q.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
+        q.rows, q.rows_per_sample = rows, rows_per_sample
+    s.groups, s.eps, s.gamma, s.beta, s.mean_rstd = groups, eps, _p(gamma), _p(beta), _p(mr)
+    a.silu, a.y, a.ldy = int(silu), _p(out), _ld(out)
+    hip.check(hip.lib().lvdhip_groupnorm_fused(C.byref(s), C.byref(a), _stream()), "groupnorm_fused")
+    return out, mr
+
+
+def groupnorm_auto(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None):
+    """(y, mean_rstd): the single-launch kernel when the sample is small, the two-stage kernels otherwise."""
+    c = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    if groupnorm_fused_ok(x1.shape[0], c, rows_per_sample, groups):
+        return groupnorm_fused(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, silu=silu, x2=x2, out=out)
     ss, mr = groupnorm_stats(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, x2=x2)
-    y = groupnorm_apply(x1, ss, rows_per_sample, silu=silu, x2=x2, out=out)
+    return groupnorm_apply(x1, ss, rows_per_sample, silu=silu, x2=x2, out=out), mr
+
+
+def groupnorm(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None, return_stats=False):
+    y, mr = groupnorm_auto(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, silu=silu, x2=x2, out=out)
     return (y, mr) if return_stats else y
 
 
@@ -212,6 +250,22 @@ def groupnorm_bwd(x1, dy, gamma, beta, mean_rstd, rows_per_sample, *, groups=32,
     c1 = x1.shape[1]
     c = c1 + (x2.shape[1] if x2 is not None else 0)
     samples = rows // rows_per_sample
+    if groupnorm_fused_ok(rows, c, rows_per_sample, groups):
+        if dx1 is None:
+            dx1 = torch.empty_like(x1)
+            assert not accumulate
+        if x2 is not None and dx2 is None:
+            dx2 = torch.empty_like(x2)
+        q = hip.GnBwdApplyParams()
+        q.x1, q.x2, q.ld1, q.ld2, q.c1, q.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
+        q.dy, q.lddy = _p(dy), _ld(dy)
+        q.rows, q.rows_per_sample, q.groups = rows, rows_per_sample, groups
+        q.gamma, q.beta, q.mean_rstd, q.silu = _p(gamma), _p(beta), _p(mean_rstd), int(silu)
+        q.dx1, q.dx2 = _p(dx1), _p(dx2)
+        q.lddx1, q.lddx2 = _ld(dx1), (_ld(dx2) if dx2 is not None else 0)
+        q.accumulate = int(accumulate)
+        hip.check(hip.lib().lvdhip_groupnorm_bwd_fused(C.byref(q), _stream()), "groupnorm_bwd_fused")
+        return dx1, dx2
     chunks = _gn_chunks(samples, rows_per_sample)
     dev = x1.device
     partial = torch.empty((samples, chunks, c, 2), dtype=torch.float32, device=dev)

@@ -187,8 +187,19 @@ def test_tconv3():
 
 
 # ----------------------------------------------------------------------------- norms
-@pytest.mark.parametrize("C,rps,samples,two", [(320, 180, 6, False), (64, 96, 4, False), (960, 45, 8, True), (128, 2 * 96, 2, False)])
-def test_groupnorm(C, rps, samples, two):
+@pytest.fixture(params=["single_launch", "two_stage"])
+def gn_path(request):
+    """Both GroupNorm implementations on every case: norm_small.hip (one launch per norm) and norm.hip (partial/finalize/apply)."""
+    saved = dict(ops._gn_fused)
+    ops._gn_fused.update(max_bytes=(1 << 40) if request.param == "single_launch" else 0)
+    yield request.param
+    ops._gn_fused.update(saved)
+
+
+@pytest.mark.parametrize("C,rps,samples,two", [(320, 180, 6, False), (64, 96, 4, False), (960, 45, 8, True), (128, 2 * 96, 2, False),
+                                                (1280, 1080, 2, False), (1920, 180, 11, True)])
+def test_groupnorm(C, rps, samples, two, gn_path):
+    assert ops.groupnorm_fused_ok(rps * samples, C, rps, 32) == (gn_path == "single_launch")
     rows = rps * samples
     x = bf(rnd(rows, C, seed=1) * 2 + 0.5)
     gamma, beta = rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.2
@@ -215,6 +226,10 @@ def test_groupnorm(C, rps, samples, two):
         got = torch.cat([d1, d2], 1)
     else:
         got, _ = ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, silu=True)
+        acc = bf(rnd(rows, C, seed=5))  # accumulate into an existing gradient
+        buf = acc.clone()
+        ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, silu=True, dx1=buf, accumulate=True)
+        close(buf, gref + acc.float(), 1.2e-2, f"groupnorm bwd accumulate C={C}")
     close(got, gref, 1e-2, f"groupnorm bwd C={C}")
 
 
