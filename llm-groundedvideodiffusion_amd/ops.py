@@ -201,12 +201,18 @@ def groupnorm_apply(x1, scale_shift, rows_per_sample, *, silu=False, x2=None, ou
 
 # Small samples take the single-launch kernels (norm_small.hip): a (sample, group) slab of at most 64 Ki elements (128 KB: its
 # second pass is an L2 hit) and a tensor small enough that the three launches of the two-stage path are launch-bound.
-_gn_fused = {"max_slab": 65536, "max_bytes": int(os.environ.get("LVD_GN_FUSED_MAX_MB", "24")) << 20}
+_gn_fused = {"max_slab": 65536, "max_bytes": int(os.environ.get("LVD_GN_FUSED_MAX_MB", "24")) << 20,
+             "max_rows_per_thread": int(os.environ.get("LVD_GN_FUSED_MAX_ROWS", "32"))}
 
 
 def groupnorm_fused_ok(rows, c, rows_per_sample, groups):
+    """A workgroup walks its slab with 256 // (cpg/2) row lanes: beyond ~32 rows per lane (the 5-D norms of the temporal layers:
+    1080+ rows per sample, only samples*groups workgroups) the walk is latency-bound and the two-stage kernels win."""
     cpg = c // groups
-    return cpg % 2 == 0 and rows_per_sample * cpg <= _gn_fused["max_slab"] and rows * c * 2 <= _gn_fused["max_bytes"]
+    if cpg % 2 or cpg > 512 or rows_per_sample * cpg > _gn_fused["max_slab"] or rows * c * 2 > _gn_fused["max_bytes"]:
+        return False
+    row_lanes = 256 // (cpg // 2)
+    return -(-rows_per_sample // row_lanes) <= _gn_fused["max_rows_per_thread"]
 
 
 def groupnorm_fused(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None):

@@ -191,7 +191,7 @@ def test_tconv3():
 def gn_path(request):
     """Both GroupNorm implementations on every case: norm_small.hip (one launch per norm) and norm.hip (partial/finalize/apply)."""
     saved = dict(ops._gn_fused)
-    ops._gn_fused.update(max_bytes=(1 << 40) if request.param == "single_launch" else 0)
+    ops._gn_fused.update(max_bytes=(1 << 40) if request.param == "single_launch" else 0, max_rows_per_thread=1 << 30)
     yield request.param
     ops._gn_fused.update(saved)
 
