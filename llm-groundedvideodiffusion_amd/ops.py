@@ -202,11 +202,11 @@ def groupnorm_apply(x1, scale_shift, rows_per_sample, *, silu=False, x2=None, ou
 # Small samples take the single-launch kernels (norm_small.hip): a (sample, group) slab of at most 64 Ki elements (128 KB: its
 # second pass is an L2 hit) and a tensor small enough that the three launches of the two-stage path are launch-bound.
 _gn_fused = {"max_slab": 65536, "max_bytes": int(os.environ.get("LVD_GN_FUSED_MAX_MB", "24")) << 20,
-             "max_rows_per_thread": int(os.environ.get("LVD_GN_FUSED_MAX_ROWS", "32"))}
+             "max_rows_per_thread": int(os.environ.get("LVD_GN_FUSED_MAX_ROWS", "16"))}
 
 
 def groupnorm_fused_ok(rows, c, rows_per_sample, groups):
-    """A workgroup walks its slab with 256 // (cpg/2) row lanes: beyond ~32 rows per lane (the 5-D norms of the temporal layers:
+    """A workgroup walks its slab with 256 // (cpg/2) row lanes: beyond ~16 rows per lane (the 5-D norms of the temporal layers:
     1080+ rows per sample, only samples*groups workgroups) the walk is latency-bound and the two-stage kernels win."""
     cpg = c // groups
     if cpg % 2 or cpg > 512 or rows_per_sample * cpg > _gn_fused["max_slab"] or rows * c * 2 > _gn_fused["max_bytes"]:
