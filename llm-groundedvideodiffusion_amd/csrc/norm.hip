@@ -47,10 +47,21 @@ LVD_DEV void gn_group_totals(const float* partial, int chunks, int c, int cpg, i
   a = 0.f; b = 0.f;
   const int n = chunks * cpg;
   const float* base = partial + ((long)s * chunks * c + g * cpg) * 2;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    int ch = i / cpg, cc = i - ch * cpg;
-    float2 v = *reinterpret_cast<const float2*>(base + ((long)ch * c + cc) * 2);
-    a += v.x; b += v.y;
+  // four pairs in flight per thread (clamped index, masked value): the partials were written by another kernel, i.e. they
+  // come from the memory side, and one pair per round trip made this tiny kernel cost 8 us
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+    float2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * 256, n - 1);
+      const int ch = i / cpg, cc = i - ch * cpg;
+      v[u] = *reinterpret_cast<const float2*>(base + ((long)ch * c + cc) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w = i0 + u * 256 < n ? 1.f : 0.f;
+      a += w * v[u].x; b += w * v[u].y;
+    }
   }
   a = wave_sum(a); b = wave_sum(b);
   if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = a; wsum[1][threadIdx.x >> 6] = b; }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblvdhip.so")
+LIB_PATH = os.environ.get("LVD_LIB", os.path.join(_HERE, "liblvdhip.so"))  # LVD_LIB: developer A/B of two builds of the library
 
 c_bf16_p = C.c_void_p
 c_f32_p = C.c_void_p
