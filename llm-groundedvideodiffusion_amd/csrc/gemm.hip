@@ -403,11 +403,10 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
     LVD_CHECK(p->K == 9 * p->cin && p->hout > 0 && p->wout > 0 && p->hin > 0 && p->win > 0 && p->M % (p->hout * p->wout) == 0,
               "gemm: bad conv dims");
   LVD_CHECK(p->m_begin >= 0 && p->m_begin < p->M, "gemm: m_begin %d outside [0, M=%d)", p->m_begin, p->M);
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("LVD_GEMM_VARIANT");  // developer knob for A/B runs (tools/gemm_bench.py)
-    variant = e ? atoi(e) : 0;
-  }
+  static const int variant = [] {  // developer knob for A/B runs (tools/gemm_bench.py); read once, thread-safe initialisation
+    const char* e = getenv("LVD_GEMM_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
   int v = p->variant ? p->variant : variant;
   int rc;
   if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
