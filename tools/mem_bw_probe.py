@@ -1,3 +1,4 @@
+"""Developer probe: achieved bandwidth of fill / copy / elementwise kernels on this GPU (sanity check of the HBM rooflines)."""
 import torch, time
 def t(fn, it=10):
     for _ in range(3): fn()
