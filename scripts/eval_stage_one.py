@@ -18,16 +18,22 @@ from lvd_amd.evaluation import ScoreBoard, evaluate_with_layout, get_prompts  # 
 MODEL_NAMES = {"gpt-4": "gpt-4-1106-preview", "gpt-4-1106-preview": "gpt-4-1106-preview", "gpt-3.5": "gpt-3.5-turbo", "gpt-3.5-turbo": "gpt-3.5-turbo"}
 
 
+FLAGS = [  # (flag, kwargs) — names and defaults of the reference's command line
+    ("--prompt-type", dict(type=str, default="lvd")),
+    ("--model", dict(choices=sorted(MODEL_NAMES), required=True)),
+    ("--template_version", dict(choices=["v0.1"], required=True)),
+    ("--skip_first_prompts", dict(type=int, default=0)),
+    ("--num_prompts", dict(type=int, default=None)),
+    ("--show-cache-access", dict(action="store_true")),
+    ("--verbose", dict(action="store_true")),
+    ("--cache-dir", dict(default="cache")),
+]
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--prompt-type", type=str, default="lvd")
-    ap.add_argument("--model", choices=sorted(MODEL_NAMES), required=True)
-    ap.add_argument("--template_version", choices=["v0.1"], required=True)
-    ap.add_argument("--skip_first_prompts", default=0, type=int)
-    ap.add_argument("--num_prompts", default=None, type=int)
-    ap.add_argument("--show-cache-access", action="store_true")
-    ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--cache-dir", default="cache")
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for flag, kw in FLAGS:
+        ap.add_argument(flag, **kw)
     args = ap.parse_args(argv)
     cache = dsl.LayoutCache(os.path.join(args.cache_dir, f"cache_{args.prompt_type.replace('lmd_', '')}_{args.template_version}_{MODEL_NAMES[args.model]}.json"))
     pairs = get_prompts(args.prompt_type, return_predicates=True)
