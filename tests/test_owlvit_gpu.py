@@ -82,18 +82,19 @@ def test_synthetic_weights_have_the_checkpoint_layout():
     assert "owlvit.vision_model.embeddings.patch_embedding.weight" in names and "box_head.dense2.bias" in names
 
 
-@pytest.mark.parametrize("n_in,n_out", [(576, 768), (320, 768), (1000, 768), (37, 64)])
-def test_resampling_table_is_pillows(n_in, n_out):
+@pytest.mark.parametrize("kind", ["bicubic", "lanczos"])
+@pytest.mark.parametrize("n_in,n_out", [(576, 768), (320, 768), (1000, 768), (37, 64), (576, 1024)])
+def test_resampling_table_is_pillows(n_in, n_out, kind):
     """One axis at a time: a 1-pixel-high (or wide) image resized along the other axis only goes through a single pass."""
     from PIL import Image
     rng = np.random.RandomState(n_in)
     line = rng.randint(0, 256, (1, n_in, 3)).astype(np.uint8)
-    bounds, coef = ops.pil_bicubic_table(n_in, n_out)
+    bounds, coef = ops.pil_resample_table(n_in, n_out, kind)
     got = np.zeros((n_out, 3), dtype=np.int64)
     for o in range(n_out):
         lo, n = bounds[o]
         got[o] = np.clip(((line[0, lo:lo + n].astype(np.int64) * coef[o, :n, None]).sum(0) + (1 << 21)) >> 22, 0, 255)
-    ref = np.asarray(Image.fromarray(line).resize((n_out, 1), Image.BICUBIC))[0]
+    ref = np.asarray(Image.fromarray(line).resize((n_out, 1), Image.BICUBIC if kind == "bicubic" else Image.LANCZOS))[0]
     assert np.array_equal(got, ref)
 
 
