@@ -124,5 +124,7 @@ class Method:
             joblib.dump(out.float().cpu().numpy(), f"{img_dir}/latents_{suffix}.joblib", compress=("bz2", 3))
             return out
         frames = (np.asarray(out[0]) * 255.0).astype(np.uint8)  # uint8 (F,H,W,3), also for the gligen method
+        if save_annotated_videos:  # the reference builds this path under the .gif name (generation/lvd.py:188-189); a sibling file here
+            vis.save_frames(f"{img_dir}/video_{suffix}_with_box", vis.draw_boxes(frames, cond.boxes, cond.phrases), formats="gif")
         vis.save_frames(f"{img_dir}/video_{suffix}", frames, formats=list(save_formats))
         return frames

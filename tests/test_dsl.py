@@ -50,3 +50,17 @@ def test_sequential_cache_and_errors(tmp_path):
     ok = "Reasoning: r\n" + "".join(f"Frame {k}: - [{{'id': 0, 'name': 'cat', 'box': [0, 0, 10, 10]}}] - moves\n" for k in range(1, 7)) + "Background keyword: room\n"
     lay = dsl.parse_layout_response("a cat", ok)
     assert lay["Frame 3"] == [{"id": 0, "name": "cat", "box": [0, 0, 10, 10]}] and lay["Background keyword"] == "room"
+
+
+def test_draw_boxes_annotates_present_objects_only(tmp_path):
+    import numpy as np
+    from lvd_amd import vis
+    frames = np.zeros((3, 40, 60, 3), dtype=np.uint8)
+    boxes = [[[0.1, 0.2, 0.5, 0.8]] * 3, [[0.0, 0.0, 0.0, 0.0], [0.6, 0.1, 0.9, 0.4], [0.6, 0.1, 0.9, 0.4]]]
+    out = vis.draw_boxes(frames, boxes, ["bear", "bird"])
+    assert out.shape == frames.shape and out.dtype == np.uint8 and frames.max() == 0  # input untouched
+    red = (out[..., 0] > 200) & (out[..., 1] < 50)
+    assert red[0, 8, 6:30].all() and not red[0, :, 36:].any()      # frame 0: only the bear's outline (bird absent: all-zero box)
+    assert red[1, 4, 36:54].all() and red[1, 8, 6:30].all()        # frame 1: both
+    vis.save_frames(str(tmp_path / "v_with_box"), out, "gif")
+    assert (tmp_path / "v_with_box.gif").exists()
