@@ -39,8 +39,9 @@ def test_lvd_run_writes_reference_file_contract(tmp_path):
     assert lvd.run(layout, seed=7, num_inference_steps=4, num_frames=24, repeat_ind=0) is None  # existing gif -> skipped
     again = lvd.run(layout, seed=7, num_inference_steps=4, num_frames=24, repeat_ind=1, loss_scale=2.5, loss_threshold=0.5, max_iter=1,
                     max_index_step=2, fg_top_p=0.25, bg_top_p=0.25, bg_weight=2.0)
-    other = lvd.run(layout, seed=8, num_inference_steps=4, num_frames=24, repeat_ind=2, max_index_step=0)
+    other = lvd.run(layout, seed=8, num_inference_steps=4, num_frames=24, repeat_ind=2, max_index_step=0, save_annotated_videos=True)
     assert np.array_equal(again, frames) and not np.array_equal(other, frames)  # output is a function of the seed
+    assert (tmp_path / "video_2_with_box.gif").exists() and np.array_equal(joblib.load(tmp_path / "video_2.joblib"), other)  # annotation is a copy
 
 
 def test_lvd_run_with_hip_vae_decoder(tmp_path):
