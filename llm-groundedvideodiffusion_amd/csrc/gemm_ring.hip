@@ -296,6 +296,18 @@ __global__ void splitk_reduce_kernel(const lvd_gemm_params p) {
   }
 }
 
+}  // namespace
+
+// slab reduction of a K-split product whose slabs are in p->ws (p->ksplit slices); shared with conv_halo.hip
+void lvd_splitk_reduce_launch(const lvd_gemm_params* p, void* stream) {
+  const long quads = (long)(p->M - p->m_begin) * (p->N / 4);
+  int rb = (int)((quads + 255) / 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, (hipStream_t)stream, *p);
+}
+
+namespace {
+
 // K split over workgroups: SLOTS = workgroups resident on the device for this geometry (one full round, never a second
 // partial one).  The wide ping-pong geometries stage 2.2x fewer bytes per flop than 128x128 and are what the small-M
 // deep-level layers (M = 1080 ... 8640, K up to 23040) need once the K split gives them enough workgroups.
@@ -318,10 +330,7 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
     case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
     default: return 1;
   }
-  long quads = (long)rows * (p.N / 4);
-  int rb = (int)((quads + 255) / 256);
-  if (rb > 4096) rb = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, p);
+  lvd_splitk_reduce_launch(&p, s);
   return 0;
 }
 

@@ -1,4 +1,4 @@
-// gemm_tile.h — pieces shared by the LDS-DMA GEMM kernels (gemm_ring.hip, gemm_pers.hip): A-operand addressing for the
+// gemm_tile.h — pieces shared by the LDS-DMA GEMM kernels (gemm_ring.hip, conv_halo.hip): A-operand addressing for the
 // four loader modes, counted vmcnt waits, and the register-direct epilogue.
 #pragma once
 #include "common.h"
@@ -65,6 +65,7 @@ LVD_DEV const lvd_bf16* a_src(const lvd_gemm_params& p, const RowInfo& r, int k0
 template <int N>
 LVD_DEV void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

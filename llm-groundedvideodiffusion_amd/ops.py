@@ -61,6 +61,7 @@ GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17)
 SPLITK_VARIANT = 20
 SPLITK_WIDE_VARIANT = 25
 TAIL_VARIANTS = (31, 37)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
+HALO_VARIANTS = (41, 45, 47)  # conv_halo.hip: whole grid / channel-chunk split-K / whole rounds + split-K tail
 _splitk_ws = {}
 
 
@@ -94,6 +95,8 @@ def _tune_gemm(p, key, out):
     p.out, p.accumulate = scratch.data_ptr(), 0
     best, best_t = 0, float("inf")
     cands = GEMM_CANDIDATES + ((SPLITK_VARIANT, SPLITK_WIDE_VARIANT) + TAIL_VARIANTS if p.ws else ())
+    if p.mode == A_CONV3X3 and p.stride == 1 and not p.upsample and not p.a2 and p.cin % 32 == 0 and p.win <= 87:
+        cands += (HALO_VARIANTS if p.ws else HALO_VARIANTS[:1])  # LDS-resident im2col (conv_halo.hip)
     for v in cands:
         p.variant = v
         _launch_gemm(p)  # warm-up (also instruction-cache / L2)

@@ -350,7 +350,7 @@ def test_elementwise():
     assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 5, 11, 17, 20])
+@pytest.mark.parametrize("variant", [1, 5, 11, 17, 20, 41, 45])
 def test_gemm_row_range(variant):
     """m_begin: only rows [m_begin, M) are produced, with absolute row indices (temb row-bias, conv geometry)."""
     M, N, K, rps, mb = 1000, 320, 1032, 250, 389
@@ -370,7 +370,7 @@ def test_gemm_row_range(variant):
     assert (outc[:500] == 0).all()
 
 
-@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37])
+@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37, 41, 47])
 def test_gemm_many_tiles(variant):
     """Grids of several rounds of tiles (tail-aware variants split them into whole rounds + a K-split remainder): short and
     ragged K, ragged M, full epilogue, GEGLU, conv loader."""
@@ -394,7 +394,7 @@ def test_gemm_many_tiles(variant):
     close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{variant} many-tiles conv")
 
 
-@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37])
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
     epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
@@ -436,7 +436,37 @@ def test_gemm_every_tile_geometry(variant):
     close(out, reft, 6e-3, f"v{variant} tconv")
 
 
-@pytest.mark.parametrize("SPLITK", [20, 25])
+@pytest.mark.parametrize("variant", [41, 45, 47])
+@pytest.mark.parametrize("n,cin,cout,h,wd", [(5, 64, 320, 12, 20), (3, 96, 160, 40, 72), (50, 32, 128, 5, 9), (2, 320, 640, 20, 36),
+                                             (1, 64, 96, 3, 87), (7, 128, 320, 1, 5)])
+def test_conv_halo(variant, n, cin, cout, h, wd):
+    """LDS-resident im2col kernel (conv_halo.hip): tiles that start and end in the middle of an image row, span several images,
+    ragged M / N tiles, one-row and one-pixel-halo images, temb row-bias + residual epilogue, and the dgrad (flipped-tap) use."""
+    x = bf(rnd(n, cin, h, wd, seed=1)).float()
+    wt = bf(conv_w(cout, cin, 2)).float()
+    b, rowb = rnd(cout, seed=3), rnd(n, cout, seed=4)
+    res = bf(rnd(n * h * wd, cout, seed=5))
+    ref = to_tokens(F.conv2d(x, wt, b, padding=1) + rowb[:, :, None, None]) * 0.5 + res.float()
+    out = ops.gemm(bf(to_tokens(x)), pack_conv(wt), bias=b, rowbias=rowb, rows_per_sample=h * wd, res=res, alpha=0.5, mode=ops.A_CONV3X3,
+                   conv=ops.ConvGeom(h, wd, h, wd), variant=variant)
+    close(out, ref, 6e-3, f"v{variant} halo conv {n}x{cin}x{h}x{wd}->{cout}")
+    old = ops.gemm(bf(to_tokens(x)), pack_conv(wt), bias=b, rowbias=rowb, rows_per_sample=h * wd, res=res, alpha=0.5, mode=ops.A_CONV3X3,
+                   conv=ops.ConvGeom(h, wd, h, wd), variant=11)
+    close(out, old, 6e-3, f"v{variant} halo vs implicit-im2col ring")
+    out2 = ops.gemm(bf(to_tokens(x)), pack_conv(wt), bias=b, rowbias=rowb, rows_per_sample=h * wd, res=res, alpha=0.5, mode=ops.A_CONV3X3,
+                    conv=ops.ConvGeom(h, wd, h, wd), variant=variant)
+    assert torch.equal(out, out2), "halo conv must be deterministic"
+    from lvd_amd.weights import pack_conv3x3_dgrad
+    xg = x.clone().requires_grad_(True)
+    y = F.conv2d(xg, wt, None, padding=1)
+    dy = bf(rnd(*y.shape, seed=6)).float()
+    (gref,) = torch.autograd.grad(y, xg, dy)
+    if cout % 32 == 0:
+        g = ops.gemm(bf(to_tokens(dy)), pack_conv3x3_dgrad(wt), mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=variant)
+        close(from_tokens(g, n, h, wd), gref, 6e-3, f"v{variant} halo dgrad")
+
+
+@pytest.mark.parametrize("SPLITK", [20, 25, 45])
 def test_gemm_split_k(SPLITK):
     """Under-filled grids (low-resolution UNet levels, M ~ 1e3, K ~ 1e4) run the K-split ring + deterministic slab
     reduction; same epilogue contract (bias, row-bias, gate, residual, accumulate, fp32 out)."""

@@ -43,7 +43,7 @@ for key, s, e in rec:
 tot = sum(v[1] for v in agg.values())
 print(f"total GEMM ms {tot:.1f} over {len(rec)} launches")
 tab = ops.gemm_autotune_table()
-for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOP', '400'))]:
     mode, M, N, K, act, cv, c1, acc = key
     tf = 2.0 * M * N * K * n / ms / 1e9
     var = [v for k, v in tab.items() if k[0] == mode and k[1] == M and k[2] == N and k[3] == K and k[4] == act]
