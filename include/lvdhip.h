@@ -62,12 +62,13 @@ enum {
   LVD_GEMM_V_SPLITK_WIDE = 25, /* K split on the 8-wave 256x320 / 256x256 geometries (small-M, long-K deep-level layers) */
   LVD_GEMM_V_RING256W_TAIL = 31,   /* RING256W on the rows that fill whole rounds of the 256 CUs, split-K on the remainder */
   LVD_GEMM_V_RING128x320_TAIL = 37, /* RING128x320 on whole rounds of 512 workgroup slots, split-K on the remainder */
-  /* 3x3 stride-1 convolutions with the im2col tile resident in LDS (conv_halo.hip): per 32-channel chunk the tile's rows + one
-     image row + one pixel of halo are staged once and the nine taps are shifted LDS views; 256x320 / 256x256, 8 waves.
+  /* 3x3 stride-1 convolutions and temporal (3,1,1) convolutions with the im2col tile resident in LDS (conv_halo.hip): per
+     32-channel chunk the rows a 512 x 160|128 tile needs for all its taps are staged once (3x3: the tile's rows + one image row
+     + one pixel of halo; temporal: 512/F pixels x all F frames) and the taps are shifted LDS views; 8 waves, 1 workgroup/CU.
      Products the kernel cannot take (stride 2, fused upsample, two sources, W > 87, Cin % 32) run the RING256W equivalents. */
   LVD_GEMM_V_CONV_HALO = 41,
   LVD_GEMM_V_CONV_HALO_SPLITK = 45, /* channel chunks split over workgroups + deterministic slab reduction */
-  LVD_GEMM_V_CONV_HALO_TAIL = 47    /* CONV_HALO on whole rounds of the 256 CUs, CONV_HALO_SPLITK on the remaining rows */
+  LVD_GEMM_V_CONV_HALO_TAIL = 47    /* CONV_HALO on whole rounds of the 256 CUs, CONV_HALO_SPLITK on the remaining tiles */
 };
 
 typedef struct {
@@ -99,8 +100,6 @@ typedef struct {
   int64_t ws_bytes;
   int32_t m_begin;         /* rows [m_begin, M) are produced (0 = the whole product); row indices stay absolute, so a product
                               can be cut into row ranges (LVD_GEMM_V_*_TAIL variants do this internally) */
-  int32_t a_rows;          /* stride-1 convolutions: rows of the source token matrix (0 = M).  Differs from M only when a product
-                              is cut into row ranges: the range ending at M < a_rows still reads the rows below it as halo */
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);

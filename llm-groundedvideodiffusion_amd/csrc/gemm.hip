@@ -314,7 +314,7 @@ int launch_gemm(const lvd_gemm_params* p, dim3 grid, hipStream_t s) {
 
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_ring.hip
 bool lvd_conv_halo_eligible(const lvd_gemm_params* p);                               // conv_halo.hip
-int lvd_conv_halo_dispatch(const lvd_gemm_params* p, void* stream, int splitk);
+int lvd_conv_halo_dispatch(const lvd_gemm_params* p, void* stream, int plan);
 
 namespace {
 
@@ -328,6 +328,8 @@ bool wide320_fills_better(const lvd_gemm_params* p) {
   };
   return time_of(320) <= time_of(256);
 }
+
+int run_with_tail(const lvd_gemm_params* p, void* stream, int v);
 
 // One launch (two for split-K) of a pinned or heuristic tile geometry over rows [m_begin, M).
 int run_variant(const lvd_gemm_params* p, void* stream, int v) {
@@ -346,12 +348,10 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   }
   const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
   // LDS-resident im2col (conv_halo.hip); products it cannot take fall through to the matching implicit-im2col geometry
-  if (v == LVD_GEMM_V_CONV_HALO || v == LVD_GEMM_V_CONV_HALO_SPLITK) {
-    if (lvd_conv_halo_eligible(p)) {
-      int rc = lvd_conv_halo_dispatch(p, stream, v == LVD_GEMM_V_CONV_HALO_SPLITK);
-      if (rc >= 0) return rc;
-      return lvd_conv_halo_dispatch(p, stream, 0);  // not splittable
-    }
+  if (v == LVD_GEMM_V_CONV_HALO || v == LVD_GEMM_V_CONV_HALO_SPLITK || v == LVD_GEMM_V_CONV_HALO_TAIL) {
+    if (lvd_conv_halo_eligible(p))
+      return lvd_conv_halo_dispatch(p, stream, v == LVD_GEMM_V_CONV_HALO ? 0 : (v == LVD_GEMM_V_CONV_HALO_SPLITK ? 1 : 2));
+    if (v == LVD_GEMM_V_CONV_HALO_TAIL) return run_with_tail(p, stream, LVD_GEMM_V_RING256W_TAIL);
     v = v == LVD_GEMM_V_CONV_HALO ? LVD_GEMM_V_RING256W : LVD_GEMM_V_SPLITK_WIDE;
   }
   if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5);
@@ -380,13 +380,10 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
     if (cus <= 0) cus = 256;
   }
   const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
-  const bool halo = v == LVD_GEMM_V_CONV_HALO_TAIL && lvd_conv_halo_eligible(p);
-  if (v == LVD_GEMM_V_CONV_HALO_TAIL && !halo) v = LVD_GEMM_V_RING256W_TAIL;
-  const bool wide = halo || v == LVD_GEMM_V_RING256W_TAIL;
-  const int base = halo ? LVD_GEMM_V_CONV_HALO : (wide ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320);
-  const int bm = halo ? 512 : (wide ? 256 : 128);
-  const int bn = halo ? (p->N % 160 == 0 ? 160 : 128) : (n320 ? 320 : (wide ? 256 : 128));
-  const int slots = cus * (wide ? 1 : (n320 ? 2 : 3));
+  const int base = v == LVD_GEMM_V_RING256W_TAIL ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320;
+  const int bm = base == LVD_GEMM_V_RING256W ? 256 : 128;
+  const int bn = n320 ? 320 : (base == LVD_GEMM_V_RING256W ? 256 : 128);
+  const int slots = cus * (base == LVD_GEMM_V_RING256W ? 1 : (n320 ? 2 : 3));
   const int rows = p->M - p->m_begin;
   const int tiles_n = (p->N + bn - 1) / bn, tiles_m = (rows + bm - 1) / bm;
   const long total = (long)tiles_m * tiles_n;
@@ -394,12 +391,10 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
   const int head_mt = (int)(full * slots / tiles_n);
   if (full < 1 || rem == 0 || rem * 10 > (long)slots * 6 || head_mt < 1 || head_mt >= tiles_m) return run_variant(p, stream, base);
   lvd_gemm_params head = *p, tail = *p;
-  head.a_rows = tail.a_rows = p->a_rows ? p->a_rows : p->M;  // the head's last rows read the tail's first rows as halo
   head.M = p->m_begin + head_mt * bm;
   tail.m_begin = head.M;
   int rc = run_variant(&head, stream, base);
   if (rc) return rc;
-  if (halo) return run_variant(&tail, stream, LVD_GEMM_V_CONV_HALO_SPLITK);
   return run_variant(&tail, stream, (p->ws && p->act == LVD_ACT_NONE) ? LVD_GEMM_V_SPLITK : LVD_GEMM_V_RING128);
 }
 
@@ -425,7 +420,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   }();
   int v = p->variant ? p->variant : variant;
   int rc;
-  if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL || v == LVD_GEMM_V_CONV_HALO_TAIL) rc = run_with_tail(p, stream, v);
+  if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
   else rc = run_variant(p, stream, v);
   LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();

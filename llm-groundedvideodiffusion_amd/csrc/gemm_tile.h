@@ -110,11 +110,18 @@ LVD_DEV RowInfo make_row(const lvd_gemm_params& p, int m, bool live) {
   return r;
 }
 
+// Row map of a wave's accumulator tile: local row (0 .. FM*32) -> token row of the output matrix (>= p.M: nothing to store).
+// The ring kernels' tiles are runs of consecutive rows; the temporal tap-GEMM (conv_halo.hip) owns P pixels x F frames.
+struct RowsLinear {
+  int mbase;
+  LVD_DEV int operator()(int local) const { return mbase + local; }
+};
+
 // (Bias and temb row-bias are not applied by the epilogues below: the kernels start their accumulators from them, see
 // ring_bias_init — the loads then overlap the DMA prologue instead of sitting, one waited-for load per 4 columns, in the
 // epilogue, where they were the larger part of its time on the short-K layers.)
-template <int FM, int FN>
-LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], int mbase, int nbase, int l31, int hi) {
+template <int FM, int FN, class RM>
+LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], const RM& rm, int nbase, int l31, int hi) {
   // The uniform tests wrap whole load loops: a load alone in a conditional block is waited for at the end of that block,
   // which would serialise the 20-40 loads of a wave (one L2 round trip each) in front of the first MFMA.
   if (p.bias) {
@@ -140,7 +147,7 @@ LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], int
   if (p.rowbias) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int m = min(mbase + i * 32 + l31, p.M - 1);
+      const int m = min(rm(i * 32 + l31), p.M - 1);
       const float* rb = p.rowbias + (long)(m / p.rows_per_sample) * p.N;
 #pragma unroll
       for (int j = 0; j < FN; ++j)
@@ -154,14 +161,19 @@ LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], int
   }
 }
 
+template <int FM, int FN>
+LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], int mbase, int nbase, int l31, int hi) {
+  ring_bias_init<FM, FN>(p, acc, RowsLinear{mbase}, nbase, l31, hi);
+}
+
 // Epilogue straight from registers.  The MFMAs are issued as D = W_frag · X_frag^T, so lane (l31) owns token row m and
 // every 4 consecutive accumulator registers are 4 consecutive output channels: bias / temb row-bias / gate / residual /
 // GEGLU are applied on 8-byte row-contiguous vectors with no LDS round trip and no barrier.
-template <int FM, int FN>
-LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int l31, int hi) {
+template <int FM, int FN, class RM>
+LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], const RM& rm, int nbase, int l31, int hi) {
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int m = mbase + i * 32 + l31;
+    const int m = rm(i * 32 + l31);
     if (m >= p.M) continue;
     if (p.act == LVD_ACT_GEGLU) {
       lvd_bf16* orow = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc;
@@ -221,8 +233,8 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
 // consecutive lanes cover consecutive bytes of a row: full 128-byte lines for the store and for the residual /
 // accumulate read.  The residual is added in fp32 to the bf16-rounded projection (what the reference's separate
 // residual add does).  Wave-private: no workgroup barrier, the LDS queue keeps one wave's accesses in order.
-template <int FM, int FN, bool GEGLU>
-LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int lane, uint32_t* buf) {
+template <int FM, int FN, bool GEGLU, class RM>
+LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], const RM& rm, int nbase, int lane, uint32_t* buf) {
   constexpr int W = GEGLU ? FN * 16 : FN * 32;  // output columns of this wave
   constexpr int S = W / 2 + 2;                  // dwords per staged row: S = 2 (mod 4) -> the 32 rows of a ds_write_b64 hit 32 distinct
                                                 // bank pairs (conflict-free); rows are 8-byte aligned, so the read side uses two b64
@@ -234,7 +246,6 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
   lvd_bf16* out = reinterpret_cast<lvd_bf16*>(p.out);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int m = mbase + i * 32 + l31;
     uint32_t* wrow = buf + l31 * S;
     // residual / accumulate operands of this 32-row block: all loads in flight before anything depends on them (the
     // stores below may alias them as far as the compiler knows, so it would otherwise chain load -> store -> load ...)
@@ -247,7 +258,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
       for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
-        const int mm = min(mbase + i * 32 + r, p.M - 1);
+        const int mm = min(rm(i * 32 + r), p.M - 1);
         const int n = min(col0 + c * 8, ncols - 8);
         rres[ps] = ldg16(p.res + (long)mm * p.ldres + n);
       }
@@ -257,7 +268,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
       for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * 64 + lane;
         const int r = idx / CPR, c = idx - r * CPR;
-        const int mm = min(mbase + i * 32 + r, p.M - 1);
+        const int mm = min(rm(i * 32 + r), p.M - 1);
         const int n = min(col0 + c * 8, ncols - 8);
         racc[ps] = ldg16(out + (long)mm * p.ldc + n);
       }
@@ -299,7 +310,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
     for (int ps = 0; ps < PASSES; ++ps) {
       const int idx = ps * 64 + lane;
       const int r = idx / CPR, c = idx - r * CPR;
-      const int mm = mbase + i * 32 + r;
+      const int mm = rm(i * 32 + r);
       const int n = col0 + c * 8;
       if (mm < p.M && n < ncols) {
         const uint2 vlo = *reinterpret_cast<const uint2*>(buf + r * S + c * 4);
@@ -335,17 +346,21 @@ LVD_DEV bool rows_epilogue_ok(const lvd_gemm_params& p) {
   return ok;
 }
 
-template <int FM, int FN>
-LVD_DEV void ring_epilogue_auto(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int lane, uint32_t* buf) {
+template <int FM, int FN, class RM>
+LVD_DEV void ring_epilogue_auto(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], const RM& rm, int nbase, int lane, uint32_t* buf) {
   if (rows_epilogue_ok(p)) {
     if (p.act == LVD_ACT_GEGLU) {
-      if constexpr (FN % 2 == 0) ring_epilogue_rows<FM, FN, true>(p, acc, mbase, nbase, lane, buf);
+      if constexpr (FN % 2 == 0) ring_epilogue_rows<FM, FN, true>(p, acc, rm, nbase, lane, buf);
     } else {
-      ring_epilogue_rows<FM, FN, false>(p, acc, mbase, nbase, lane, buf);
+      ring_epilogue_rows<FM, FN, false>(p, acc, rm, nbase, lane, buf);
     }
   } else {
-    ring_epilogue<FM, FN>(p, acc, mbase, nbase, lane & 31, lane >> 5);
+    ring_epilogue<FM, FN>(p, acc, rm, nbase, lane & 31, lane >> 5);
   }
+}
+template <int FM, int FN>
+LVD_DEV void ring_epilogue_auto(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], int mbase, int nbase, int lane, uint32_t* buf) {
+  ring_epilogue_auto<FM, FN>(p, acc, RowsLinear{mbase}, nbase, lane, buf);
 }
 
 // K-split planning shared by the split-K launchers and the geometry choice.  Cost of c slices in "K elements of one

@@ -466,6 +466,31 @@ def test_conv_halo(variant, n, cin, cout, h, wd):
         close(from_tokens(g, n, h, wd), gref, 6e-3, f"v{variant} halo dgrad")
 
 
+@pytest.mark.parametrize("variant", [41, 45, 47])
+@pytest.mark.parametrize("B,Fr,hw,cin,cout", [(2, 24, 45, 64, 320), (1, 24, 100, 96, 160), (3, 5, 12, 32, 128), (1, 16, 1024, 64, 96),
+                                              (2, 2, 300, 128, 320), (1, 24, 21, 320, 640)])
+def test_tconv_halo(variant, B, Fr, hw, cin, cout):
+    """LDS-resident temporal conv (conv_halo.hip, tile = 512/F pixels x all frames): pixel blocks that do not divide HW, several
+    clips, frame counts that do not divide 512, bias + residual epilogue, split-K slabs through the row map, determinism."""
+    x = bf(rnd(B * Fr * hw, cin, seed=1))
+    wtc = bf(rnd(cout, cin, 3, seed=2, scale=0.05)).float()
+    b = rnd(cout, seed=3)
+    res = bf(rnd(B * Fr * hw, cout, seed=4))
+    x5 = x.float().reshape(B, Fr, hw, cin).permute(0, 3, 1, 2)[..., None]
+    ref = F.conv3d(x5, wtc[..., None, None], b, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(B * Fr * hw, cout) * 0.5 + res.float()
+    wp = bf(wtc.permute(0, 2, 1).reshape(cout, 3 * cin).contiguous())
+    run = lambda v: ops.gemm(x, wp, bias=b, res=res, alpha=0.5, mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=v)
+    out = run(variant)
+    close(out, ref, 6e-3, f"v{variant} halo tconv B{B} F{Fr} hw{hw} {cin}->{cout}")
+    close(out, run(11), 6e-3, f"v{variant} halo tconv vs ring")
+    assert torch.equal(out, run(variant)), "halo tconv must be deterministic"
+    acc = bf(rnd(B * Fr * hw, cout, seed=5))
+    ref2 = acc.float() + ref - res.float() * 1.0 + res.float()  # accumulate adds onto the existing output
+    o2 = acc.clone()
+    ops.gemm(x, wp, bias=b, res=res, alpha=0.5, mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=variant, out=o2, accumulate=True)
+    close(o2, ref2, 8e-3, f"v{variant} halo tconv accumulate")
+
+
 @pytest.mark.parametrize("SPLITK", [20, 25, 45])
 def test_gemm_split_k(SPLITK):
     """Under-filled grids (low-resolution UNet levels, M ~ 1e3, K ~ 1e4) run the K-split ring + deterministic slab
