@@ -34,27 +34,6 @@ constexpr int HALO_BM = 512;
 // image rows (whole wave-instructions of 16 rows per wave): 3x3 conv 768 >= 512 + 2·(W+1) for W <= 87; temporal conv F·P <= 512
 template <int MODE> constexpr int img_rows() { return MODE == LVD_A_CONV3X3 ? 768 : 512; }
 
-typedef __attribute__((ext_vector_type(4))) int v4i;
-
-// One wave-wide LDS-DMA instruction: 64 lanes x 16 bytes from (descriptor base + per-lane byte offset + scalar byte offset)
-// to the lane-linear 1 KB at LDS byte address `dst`.  Issued as inline assembly: with the builtin the compiler cannot prove
-// that the DMA in flight does not alias the stage being read and puts s_waitcnt vmcnt(0) in front of the first ds_read of
-// every phase, which turns the counted waits below into full drains.  M0 (the DMA's LDS base) is saved and restored inside
-// the statement (it is compiler-reserved); s_nop 4 covers a VALU-written SGPR operand, s_nop 0 the M0 write.
-LVD_DEV void dma16(v4i rsrc, int voff, int soff, unsigned dst) {
-  unsigned keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(rsrc), "s"(dst), "s"(soff)
-               : "memory");
-}
-LVD_DEV v4i make_rsrc(const void* base) {
-  const unsigned long b = reinterpret_cast<unsigned long>(base);
-  v4i r = {(int)(unsigned)b, (int)((b >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
-  return r;
-}
-LVD_DEV unsigned lds_addr(const void* q) { return (unsigned)(unsigned long)(lptr_t)q; }
-
 // Geometry of one tile (wave-uniform scalars).  Image row r (0 .. img_rows) <-> token row; tile row l (0 .. 511) <-> token
 // row of the output and image row l + lead.
 template <int MODE>

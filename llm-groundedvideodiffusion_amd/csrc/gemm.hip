@@ -354,6 +354,8 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
     if (v == LVD_GEMM_V_CONV_HALO_TAIL) return run_with_tail(p, stream, LVD_GEMM_V_RING256W_TAIL);
     v = v == LVD_GEMM_V_CONV_HALO ? LVD_GEMM_V_RING256W : LVD_GEMM_V_SPLITK_WIDE;
   }
+  if (v == LVD_GEMM_V_RING256W_ADMA) return lvd_gemm_ring_dispatch(p, stream, 100 + (n320 ? 4 : 5));
+  if (v == LVD_GEMM_V_SPLITK_WIDE_ADMA) return lvd_gemm_ring_dispatch(p, stream, 100 + (n320 && wide320_fills_better(p) ? 24 : 25));
   if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5);
   if (v == 14) return lvd_gemm_ring_dispatch(p, stream, 8);
   if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20);
@@ -380,10 +382,11 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
     if (cus <= 0) cus = 256;
   }
   const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
-  const int base = v == LVD_GEMM_V_RING256W_TAIL ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320;
-  const int bm = base == LVD_GEMM_V_RING256W ? 256 : 128;
-  const int bn = n320 ? 320 : (base == LVD_GEMM_V_RING256W ? 256 : 128);
-  const int slots = cus * (base == LVD_GEMM_V_RING256W ? 1 : (n320 ? 2 : 3));
+  const bool wide = v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING256W_ADMA_TAIL;
+  const int base = v == LVD_GEMM_V_RING256W_ADMA_TAIL ? LVD_GEMM_V_RING256W_ADMA : (wide ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320);
+  const int bm = wide ? 256 : 128;
+  const int bn = n320 ? 320 : (wide ? 256 : 128);
+  const int slots = cus * (wide ? 1 : (n320 ? 2 : 3));
   const int rows = p->M - p->m_begin;
   const int tiles_n = (p->N + bn - 1) / bn, tiles_m = (rows + bm - 1) / bm;
   const long total = (long)tiles_m * tiles_n;
@@ -420,7 +423,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   }();
   int v = p->variant ? p->variant : variant;
   int rc;
-  if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
+  if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL || v == LVD_GEMM_V_RING256W_ADMA_TAIL) rc = run_with_tail(p, stream, v);
   else rc = run_variant(p, stream, v);
   LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();

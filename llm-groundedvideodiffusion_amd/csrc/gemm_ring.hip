@@ -29,8 +29,13 @@
 namespace {
 
 // WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
-template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false>
+// ADMA (plain loader, K % RBK == 0): the LDS-DMA is issued as inline assembly from raw buffer descriptors (gemm_tile.h dma16),
+// so the compiler neither sees a pending LDS write (no vmcnt(0) in front of every phase's first ds_read: the counted waits
+// really leave STAGES-2 tiles in flight) nor keeps 64-bit source addresses; rows / columns past M / N are clamped (their
+// products are never stored), K tiles past the end re-read the last one.
+template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false, bool ADMA = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
+  static_assert(!ADMA || (MODE == LVD_A_PLAIN && PP), "asm DMA: plain loader, ping-pong geometries only");
   constexpr int NW = WM * WN;
   constexpr int RCH = RBK / 8;                            // 16-byte chunks per tile row (4: 64 B rows, 8: full 128 B lines)
   constexpr int RPI = 64 / RCH;                          // tile rows covered by one wave-wide glds instruction
@@ -41,7 +46,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   constexpr int BPW = (BINS + NW - 1) / NW;              // B instructions per wave (padded: every wave issues BPW)
   static_assert(AINS % NW == 0, "BM must be a multiple of RPI * waves");
   constexpr int LPS = APW + BPW;                         // glds per wave per stage (uniform -> one vmcnt immediate)
-  __shared__ uint4 lds[STAGES * TILE];
+  constexpr int BIASQ = ADMA ? (BN * 4 + 1023) / 1024 * 64 : 0;               // ADMA: the tile's bias row is staged in LDS by the DMA engine too
+  __shared__ uint4 lds[STAGES * TILE + BIASQ];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,26 +82,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   auto swz = [](int row, int c) { return RCH == 4 ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 1) & 7)); };
 
   RowInfo ar[APW];
-#pragma unroll
-  for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, p.m_begin + tm * BM + (wave * APW + q) * RPI + rsub, true);
   long woff[BPW];
   bool wvalid[BPW];
   int bins[BPW];
+  [[maybe_unused]] int av1[APW], av2[APW], bv[BPW];
+  [[maybe_unused]] v4i rsA1, rsA2, rsB;
+  if constexpr (ADMA) {
+    rsA1 = make_rsrc(p.a1);
+    rsA2 = make_rsrc(p.a2);
+    rsB = make_rsrc(p.w);
 #pragma unroll
-  for (int t = 0; t < BPW; ++t) {
-    int b = wave + NW * t;
-    bool real = b < BINS;
-    bins[t] = real ? b : BINS - 1;  // padding instruction re-stages the last 16 rows (same data, harmless)
-    int n = tn * BN + bins[t] * RPI + rsub;
-    wvalid[t] = n < p.N;
-    woff[t] = (long)n * p.K;
+    for (int q = 0; q < APW; ++q) {
+      const int r = (wave * APW + q) * RPI + rsub;
+      const int m = min(p.m_begin + tm * BM + r, p.M - 1);
+      av1[q] = m * p.lda1 * 2 + swz(r, cpos) * 16;
+      av2[q] = m * p.lda2 * 2 + swz(r, cpos) * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < BPW; ++t) {
+      const int b = wave + NW * t;
+      bins[t] = b < BINS ? b : BINS - 1;
+      const int r = bins[t] * RPI + rsub;
+      bv[t] = min(tn * BN + r, p.N - 1) * p.K * 2 + swz(r, cpos) * 16;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < APW; ++q) ar[q] = make_row<MODE>(p, p.m_begin + tm * BM + (wave * APW + q) * RPI + rsub, true);
+#pragma unroll
+    for (int t = 0; t < BPW; ++t) {
+      int b = wave + NW * t;
+      bool real = b < BINS;
+      bins[t] = real ? b : BINS - 1;  // padding instruction re-stages the last 16 rows (same data, harmless)
+      int n = tn * BN + bins[t] * RPI + rsub;
+      wvalid[t] = n < p.N;
+      woff[t] = (long)n * p.K;
+    }
   }
 
   // one wave-wide LDS-DMA instruction of tile kt (idx < APW: A rows, else B rows)
   auto stage_one = [&](int kt, int slot, int idx) {
     uint4* A = lds + slot * TILE;
     uint4* B = A + BM * RCH;
-    if (idx < APW) {
+    if constexpr (ADMA) {
+      const int kb = min(kbeg + kt * RBK, p.K - RBK);  // tiles past the end (uniform vmcnt bookkeeping) re-read the last one
+      if (idx < APW) {
+        const bool s2 = kb >= p.c1;                    // a K tile lies in one source (c1 % RBK == 0)
+        dma16(s2 ? rsA2 : rsA1, s2 ? av2[idx] : av1[idx], (s2 ? kb - p.c1 : kb) * 2, lds_addr(A + (wave * APW + idx) * RPI * RCH));
+      } else {
+        dma16(rsB, bv[idx - APW], kb * 2, lds_addr(B + bins[idx - APW] * RPI * RCH));
+      }
+    } else if (idx < APW) {
       const int q = idx;
       const int k0 = kbeg + kt * RBK + swz((wave * APW + q) * RPI + rsub, cpos) * 8;
       const lvd_bf16* src = a_src<MODE>(p, ar[q], k0, klim);
@@ -113,14 +149,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   };
 
   const int nk = (max(klim - kbeg, 0) + RBK - 1) / RBK;
+
+  if constexpr (ADMA && !SPLITK) {
+    if (p.bias && wave * 256 < BN * 4) {
+      const int off = min(tn * BN * 4 + wave * 1024 + lane * 16, p.N * 4 - 16);
+      dma16(make_rsrc(p.bias), off, 0, lds_addr(lds + STAGES * TILE + wave * 64));
+    }
+  }
   // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) stage(s, s);
-
   // accumulators start from bias + temb row-bias (the K-split slices start from zero: their reduce kernel adds them); the
-  // loads are issued behind the DMA prologue so both latencies overlap
+  // loads are issued behind the DMA prologue so both latencies overlap.  ADMA: a burst of ordinary loads between the asm
+  // statements cannot be scheduled around them and spilled ~80 registers; the bias row of the tile (BN floats) rides the DMA
+  // path instead — the oldest DMA of waves 0-1, so every counted wait below covers it — and is read from LDS after the
+  // first barrier.
   f32x16 acc[FM][FN];
-  if (SPLITK) {
+  constexpr bool LDS_BIAS = ADMA && !SPLITK;
+  if (SPLITK || LDS_BIAS) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -144,6 +190,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     const int group = wave >> 2;
     wait_vmcnt<(STAGES - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (LDS_BIAS) {
+      if (p.bias) {
+        const uint4* bq = lds + STAGES * TILE + wn * FN * 8 + hi;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, bq[j * 8 + 2 * q]);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
+          }
+      }
+    }
     if (group == 1) __builtin_amdgcn_s_barrier();
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -311,7 +372,7 @@ namespace {
 // K split over workgroups: SLOTS = workgroups resident on the device for this geometry (one full round, never a second
 // partial one).  The wide ping-pong geometries stage 2.2x fewer bytes per flop than 128x128 and are what the small-M
 // deep-level layers (M = 1080 ... 8640, K up to 23040) need once the K split gives them enough workgroups.
-template <int WM, int WN, int FM, int FN, int STAGES, bool PP, int SLOTS>
+template <int WM, int WN, int FM, int FN, int STAGES, bool PP, int SLOTS, bool ADMA = false>
 int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   lvd_gemm_params p = *pp;
@@ -324,7 +385,7 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   p.ksplit = ks;
   dim3 grid(tiles * ks), block(64 * WM * WN);
   switch (p.mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, 32, true, PP, ADMA>), grid, block, 0, s, p); break;
     case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
     case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
     case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
@@ -334,13 +395,13 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   return 0;
 }
 
-template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32, bool PP = false>
+template <int WM, int WN, int FM, int FN, int STAGES, int RBK = 32, bool PP = false, bool ADMA = false>
 int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   dim3 grid(tiles), block(64 * WM * WN);
   switch (p->mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, false, PP, ADMA>), grid, block, 0, s, *p); break;
     case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
     case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
     case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
@@ -360,6 +421,21 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
     int rc = launch_splitk<2, 2, 2, 2, 3, false, 768>(p, s);
     if (rc >= 0) return rc;
     geometry = 0;  // not splittable (no workspace / GEGLU / too little K): plain 128x128 ring
+  }
+  // +100: the asm-DMA instantiation of the same geometry (plain loader, K % 32 == 0, whole K tiles per source)
+  const bool adma_ok = p->mode == LVD_A_PLAIN && p->K % 32 == 0 && p->rowbias == nullptr && p->N >= 4 && (p->a2 == nullptr || p->c1 % 32 == 0) &&
+                       (long)p->M * (p->lda1 > p->lda2 ? p->lda1 : p->lda2) < (1L << 30) && (long)p->N * p->K < (1L << 30);
+  if (geometry >= 100) {
+    geometry -= 100;
+    if (adma_ok) {
+      if (geometry == 24 || geometry == 25) {
+        int rc = geometry == 24 ? launch_splitk<4, 2, 2, 5, 3, true, 256, true>(p, s) : launch_splitk<4, 2, 2, 4, 3, true, 256, true>(p, s);
+        if (rc >= 0) return rc;
+        geometry = geometry == 24 ? 4 : 5;
+      }
+      if (geometry == 4) return launch_ring<4, 2, 2, 5, 3, 32, true, true>(p, s);
+      if (geometry == 5) return launch_ring<4, 2, 2, 4, 3, 32, true, true>(p, s);
+    }
   }
   if (geometry == 24 || geometry == 25) {  // K split on the 8-wave ping-pong geometries (256x320 / 256x256), 1 workgroup per CU
     int rc = geometry == 24 ? launch_splitk<4, 2, 2, 5, 3, true, 256>(p, s) : launch_splitk<4, 2, 2, 4, 3, true, 256>(p, s);

@@ -1,0 +1,58 @@
+"""Developer probe: plain-loader GEMM variants on the linear shapes of the zeroscope step, interleaved A/B rounds in one process.
+    python tools/lin_bench.py [--variants 11,31,25,51,57,55] [--rounds 5]"""
+import argparse
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import lvd_amd  # noqa: F401
+from lvd_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", default="11,31,25,51,57,55")
+ap.add_argument("--rounds", type=int, default=5)
+args = ap.parse_args()
+variants = [int(v) for v in args.variants.split(",")]
+dev = "cuda"
+# (M, N, K, geglu, residual) — the heaviest plain-loader products of a guided step (tools/step_gemm_profile.py)
+shapes = [(138240, 2560, 320, 1, 0), (138240, 320, 320, 0, 1), (4320, 1280, 1280, 0, 1), (34560, 5120, 640, 1, 0), (8640, 10240, 1280, 1, 0),
+          (34560, 640, 640, 0, 1), (17280, 640, 640, 0, 1), (8640, 1280, 1280, 0, 1), (138240, 960, 320, 0, 0), (34560, 1920, 640, 0, 0),
+          (138240, 320, 1280, 0, 1), (8640, 1280, 5120, 0, 1), (69120, 320, 320, 0, 1), (34560, 640, 2560, 0, 1), (8640, 3840, 1280, 0, 0),
+          (4320, 1280, 10240, 0, 1), (1080, 1280, 1280, 0, 1)]
+
+
+def rnd(*s):
+    return torch.randn(*s, device=dev).bfloat16()
+
+
+for M, N, K, geglu, hasres in shapes:
+    a, w = rnd(M, K), rnd(N, K) * 0.03
+    bias = torch.randn(N, device=dev)
+    res = rnd(M, N) if hasres else None
+    run = lambda v: ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_GEGLU if geglu else ops.ACT_NONE, variant=v)
+    ref = run(11).float()
+    times = {v: [] for v in variants}
+    errs = {}
+    for v in variants:
+        out = run(v).float()
+        errs[v] = ((out - ref).norm() / ref.norm()).item()
+        run(v)
+    torch.cuda.synchronize()
+    for _ in range(args.rounds):
+        for v in variants:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                run(v)
+            e.record()
+            e.synchronize()
+            times[v].append(s.elapsed_time(e) / 3 * 1e3)
+    fl = 2.0 * M * N * K
+    line = f"M={M:6d} N={N:5d} K={K:5d} g{geglu} r{hasres} |"
+    best = min(variants, key=lambda v: statistics.median(times[v]))
+    for v in variants:
+        us = statistics.median(times[v])
+        line += f" v{v}: {us:7.1f}us {fl / us / 1e6:5.0f}TF e={errs[v]:.0e}{'*' if v == best else ' '}|"
+    print(line, flush=True)
