@@ -66,9 +66,10 @@ enum {
      32-channel chunk the rows a 512 x 160|128 tile needs for all its taps are staged once (3x3: the tile's rows + one image row
      + one pixel of halo; temporal: 512/F pixels x all F frames) and the taps are shifted LDS views; 8 waves, 1 workgroup/CU.
      Products the kernel cannot take (stride 2, fused upsample, two sources, W > 87, Cin % 32) run the RING256W equivalents. */
-  LVD_GEMM_V_RING256W_ADMA = 51,       /* RING256W with the LDS-DMA issued from buffer descriptors in inline assembly (plain loader) */
-  LVD_GEMM_V_SPLITK_WIDE_ADMA = 55,    /* SPLITK_WIDE, same */
-  LVD_GEMM_V_RING256W_ADMA_TAIL = 57,  /* RING256W_TAIL, same */
+  /* + LVD_GEMM_V_ADMA on a RING128 / RING256N / RING256W / RING128x320 / SPLITK / SPLITK_WIDE / *_TAIL variant: the same
+     geometry with its LDS-DMA issued from buffer descriptors in inline assembly, counted waits that really leave tiles in
+     flight, bias row staged by the DMA engine (plain loader, K % 32 == 0; anything else runs the base variant) */
+  LVD_GEMM_V_ADMA = 100,
   LVD_GEMM_V_CONV_HALO = 41,
   LVD_GEMM_V_CONV_HALO_SPLITK = 45, /* channel chunks split over workgroups + deterministic slab reduction */
   LVD_GEMM_V_CONV_HALO_TAIL = 47    /* CONV_HALO on whole rounds of the 256 CUs, CONV_HALO_SPLITK on the remaining tiles */

@@ -354,15 +354,15 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
     if (v == LVD_GEMM_V_CONV_HALO_TAIL) return run_with_tail(p, stream, LVD_GEMM_V_RING256W_TAIL);
     v = v == LVD_GEMM_V_CONV_HALO ? LVD_GEMM_V_RING256W : LVD_GEMM_V_SPLITK_WIDE;
   }
-  if (v == LVD_GEMM_V_RING256W_ADMA) return lvd_gemm_ring_dispatch(p, stream, 100 + (n320 ? 4 : 5));
-  if (v == LVD_GEMM_V_SPLITK_WIDE_ADMA) return lvd_gemm_ring_dispatch(p, stream, 100 + (n320 && wide320_fills_better(p) ? 24 : 25));
-  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5);
+  const int adma = v >= LVD_GEMM_V_ADMA ? 100 : 0;  // asm buffer-DMA instantiation of the same ring geometry (gemm_ring.hip)
+  if (adma) v -= LVD_GEMM_V_ADMA;
+  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5 + (v <= 6 ? adma : 0));
   if (v == 14) return lvd_gemm_ring_dispatch(p, stream, 8);
-  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20);
-  if (v == LVD_GEMM_V_SPLITK_WIDE) return lvd_gemm_ring_dispatch(p, stream, n320 && wide320_fills_better(p) ? 24 : 25);
-  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, n320 ? 12 : 0);
-  if (v == 11) return lvd_gemm_ring_dispatch(p, stream, n320 ? 4 : 5);
-  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, (p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3);
+  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20 + adma);
+  if (v == LVD_GEMM_V_SPLITK_WIDE) return lvd_gemm_ring_dispatch(p, stream, (n320 && wide320_fills_better(p) ? 24 : 25) + adma);
+  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 12 : 0) + adma);
+  if (v == 11) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 4 : 5) + adma);
+  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, ((p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3) + adma);
   if (v == 1) return launch_gemm<32, 3>(p, grid, s);
   if (v == 2) return launch_gemm<32, 4>(p, grid, s);
   return launch_gemm<64, 2>(p, grid, s);
@@ -382,8 +382,10 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
     if (cus <= 0) cus = 256;
   }
   const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
-  const bool wide = v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING256W_ADMA_TAIL;
-  const int base = v == LVD_GEMM_V_RING256W_ADMA_TAIL ? LVD_GEMM_V_RING256W_ADMA : (wide ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320);
+  const int adma = v >= LVD_GEMM_V_ADMA ? LVD_GEMM_V_ADMA : 0;
+  v -= adma;
+  const bool wide = v == LVD_GEMM_V_RING256W_TAIL;
+  const int base = (wide ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320) + adma;
   const int bm = wide ? 256 : 128;
   const int bn = n320 ? 320 : (wide ? 256 : 128);
   const int slots = cus * (wide ? 1 : (n320 ? 2 : 3));
@@ -398,7 +400,7 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
   tail.m_begin = head.M;
   int rc = run_variant(&head, stream, base);
   if (rc) return rc;
-  return run_variant(&tail, stream, (p->ws && p->act == LVD_ACT_NONE) ? LVD_GEMM_V_SPLITK : LVD_GEMM_V_RING128);
+  return run_variant(&tail, stream, ((p->ws && p->act == LVD_ACT_NONE) ? LVD_GEMM_V_SPLITK : LVD_GEMM_V_RING128) + adma);
 }
 
 }  // namespace
@@ -423,7 +425,8 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   }();
   int v = p->variant ? p->variant : variant;
   int rc;
-  if (v == LVD_GEMM_V_RING256W_TAIL || v == LVD_GEMM_V_RING128x320_TAIL || v == LVD_GEMM_V_RING256W_ADMA_TAIL) rc = run_with_tail(p, stream, v);
+  const int vb = v >= LVD_GEMM_V_ADMA ? v - LVD_GEMM_V_ADMA : v;
+  if (vb == LVD_GEMM_V_RING256W_TAIL || vb == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
   else rc = run_variant(p, stream, v);
   LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();

@@ -35,7 +35,7 @@ namespace {
 // products are never stored), K tiles past the end re-read the last one.
 template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false, bool ADMA = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
-  static_assert(!ADMA || (MODE == LVD_A_PLAIN && PP), "asm DMA: plain loader, ping-pong geometries only");
+  static_assert(!ADMA || (MODE == LVD_A_PLAIN && RBK == 32), "asm DMA: plain loader, 32-wide K tiles");
   constexpr int NW = WM * WN;
   constexpr int RCH = RBK / 8;                            // 16-byte chunks per tile row (4: 64 B rows, 8: full 128 B lines)
   constexpr int RPI = 64 / RCH;                          // tile rows covered by one wave-wide glds instruction
@@ -177,6 +177,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     ring_bias_init<FM, FN>(p, acc, p.m_begin + tm * BM + wm * FM * 32, tn * BN + wn * FN * 32, l31, hi);
   }
 
+  auto acc_from_lds_bias = [&]() {  // after a barrier that follows the waves' wait for the bias DMA
+    if (p.bias) {
+      const uint4* bq = lds + STAGES * TILE + wn * FN * 8 + hi;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = __builtin_bit_cast(f32x4, bq[j * 8 + 2 * q]);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
+        }
+    }
+  };
 
   if constexpr (PP) {
     // Ping-pong schedule for the 8-wave geometries (two waves per SIMD).  In the lock-step loop below both waves of a
@@ -190,21 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     const int group = wave >> 2;
     wait_vmcnt<(STAGES - 2) * LPS>();
     __builtin_amdgcn_s_barrier();
-    if constexpr (LDS_BIAS) {
-      if (p.bias) {
-        const uint4* bq = lds + STAGES * TILE + wn * FN * 8 + hi;
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = __builtin_bit_cast(f32x4, bq[j * 8 + 2 * q]);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
-          }
-      }
-    }
+    if constexpr (LDS_BIAS) acc_from_lds_bias();
     if (group == 1) __builtin_amdgcn_s_barrier();
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -248,6 +249,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     }
     if (group == 0) __builtin_amdgcn_s_barrier();
   } else {
+    if constexpr (LDS_BIAS) {  // the bias DMA is older than the STAGES-1 prologue tiles
+      wait_vmcnt<(STAGES - 1) * LPS>();
+      __builtin_amdgcn_s_barrier();
+      acc_from_lds_bias();
+    }
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
       // tile kt has landed once at most (STAGES-2) younger stages are still outstanding
@@ -417,25 +423,39 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
 //           8 = 256x256x64 8 waves (2 stages), 12 = 128x320 (2 stages), 20 = split-K 128x128
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry) {
   hipStream_t s = (hipStream_t)stream;
-  if (geometry == 20) {
-    int rc = launch_splitk<2, 2, 2, 2, 3, false, 768>(p, s);
-    if (rc >= 0) return rc;
-    geometry = 0;  // not splittable (no workspace / GEGLU / too little K): plain 128x128 ring
-  }
-  // +100: the asm-DMA instantiation of the same geometry (plain loader, K % 32 == 0, whole K tiles per source)
-  const bool adma_ok = p->mode == LVD_A_PLAIN && p->K % 32 == 0 && p->rowbias == nullptr && p->N >= 4 && (p->a2 == nullptr || p->c1 % 32 == 0) &&
+  // +100: the asm-DMA instantiation of the same geometry (plain loader, K % 32 == 0, whole K tiles per source, no temb row-bias)
+  const bool adma_ok = p->mode == LVD_A_PLAIN && p->K % 32 == 0 && p->rowbias == nullptr && p->N >= 4 &&
+                       (p->a2 == nullptr || p->c1 % 32 == 0) &&
                        (long)p->M * (p->lda1 > p->lda2 ? p->lda1 : p->lda2) < (1L << 30) && (long)p->N * p->K < (1L << 30);
   if (geometry >= 100) {
     geometry -= 100;
     if (adma_ok) {
+      if (geometry == 20) {
+        int rc = launch_splitk<2, 2, 2, 2, 3, false, 768, true>(p, s);
+        if (rc >= 0) return rc;
+        geometry = 0;
+      }
       if (geometry == 24 || geometry == 25) {
         int rc = geometry == 24 ? launch_splitk<4, 2, 2, 5, 3, true, 256, true>(p, s) : launch_splitk<4, 2, 2, 4, 3, true, 256, true>(p, s);
         if (rc >= 0) return rc;
         geometry = geometry == 24 ? 4 : 5;
       }
-      if (geometry == 4) return launch_ring<4, 2, 2, 5, 3, 32, true, true>(p, s);
-      if (geometry == 5) return launch_ring<4, 2, 2, 4, 3, 32, true, true>(p, s);
+      switch (geometry) {
+        case 0: return launch_ring<2, 2, 2, 2, 3, 32, false, true>(p, s);
+        case 1: return launch_ring<2, 2, 2, 2, 4, 32, false, true>(p, s);
+        case 2: return launch_ring<4, 1, 2, 5, 3, 32, false, true>(p, s);
+        case 3: return launch_ring<4, 1, 2, 4, 3, 32, false, true>(p, s);
+        case 4: return launch_ring<4, 2, 2, 5, 3, 32, true, true>(p, s);
+        case 5: return launch_ring<4, 2, 2, 4, 3, 32, true, true>(p, s);
+        case 12: return launch_ring<2, 2, 2, 5, 2, 32, false, true>(p, s);
+        default: break;
+      }
     }
+  }
+  if (geometry == 20) {
+    int rc = launch_splitk<2, 2, 2, 2, 3, false, 768>(p, s);
+    if (rc >= 0) return rc;
+    geometry = 0;  // not splittable (no workspace / GEGLU / too little K): plain 128x128 ring
   }
   if (geometry == 24 || geometry == 25) {  // K split on the 8-wave ping-pong geometries (256x320 / 256x256), 1 workgroup per CU
     int rc = geometry == 24 ? launch_splitk<4, 2, 2, 5, 3, true, 256>(p, s) : launch_splitk<4, 2, 2, 4, 3, true, 256>(p, s);

@@ -57,10 +57,10 @@ class ConvGeom:
 # (M, N, K, loader): short-K linears favour many small workgroups, long-K convs the LDS-DMA ring, and the
 # 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
-GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 51)
+GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117)  # 100 + v: asm-DMA instantiation of ring variant v
 SPLITK_VARIANT = 20
 SPLITK_WIDE_VARIANT = 25
-TAIL_VARIANTS = (31, 37, 55, 57)  # 55 / 57: split-K wide / tail on the asm-DMA ring  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
+TAIL_VARIANTS = (31, 37, 120, 125, 131, 137)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
 HALO_VARIANTS = (41, 45, 47)  # conv_halo.hip: whole grid / channel-chunk split-K / whole rounds + split-K tail
 _splitk_ws = {}
 

@@ -11,7 +11,7 @@ import lvd_amd  # noqa: F401
 from lvd_amd import ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variants", default="11,31,25,51,57,55")
+ap.add_argument("--variants", default="5,105,9,109,17,117,111,131,125")
 ap.add_argument("--rounds", type=int, default=5)
 args = ap.parse_args()
 variants = [int(v) for v in args.variants.split(",")]
