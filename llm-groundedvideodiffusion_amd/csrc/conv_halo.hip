@@ -43,6 +43,7 @@ struct TapGeo {
   int need;    // image rows that hold data
   int P, base, pix0, pixn;  // tconv: pixels per tile, token row of (b, f = 0, pixel 0), first pixel, pixels in this tile
   int hw, magic;            // magic = ceil(2^20 / P): r / P == (r · magic) >> 20 exactly for r < 768, P <= 256
+  int up, W, HWo;           // conv with a nearest-x2 upsampled source: output (= virtual input) width, rows per image
   LVD_DEV int frame_of(int r) const { return (r * magic) >> 20; }
   LVD_DEV void init(const lvd_gemm_params& p, int tm) {
     if (MODE == LVD_A_CONV3X3) {
@@ -50,6 +51,7 @@ struct TapGeo {
       lead = p.win + 1;
       need = HALO_BM + 2 * lead;
       P = base = pix0 = pixn = hw = magic = 0;
+      up = p.upsample; W = p.win; HWo = p.hin * p.win;
     } else {
       P = HALO_BM / p.frames;
       magic = ((1 << 20) + P - 1) / P;
@@ -62,13 +64,19 @@ struct TapGeo {
       need = p.frames * P;
       m0 = 0;
       lead = 0;
+      up = W = HWo = 0;
     }
   }
   // token row of image row r, or -1
   LVD_DEV int src_row(int r, int arows) const {
     if (MODE == LVD_A_CONV3X3) {
       const int g = m0 - lead + r;
-      return (r < need && g >= 0 && g < arows) ? g : -1;
+      if (!(r < need && g >= 0 && g < arows)) return -1;
+      if (!up) return g;
+      // the source is stored at half resolution: virtual pixel (iy, ix) of image n reads stored pixel (iy/2, ix/2)
+      const int n = g / HWo, rem = g - n * HWo;
+      const int iy = rem / W, ix = rem - iy * W;
+      return n * (HWo >> 2) + (iy >> 1) * (W >> 1) + (ix >> 1);
     } else {
       const int f = frame_of(r), pp = r - f * P;
       return (r < need && pp < pixn) ? base + f * hw + pix0 + pp : -1;
@@ -437,7 +445,7 @@ bool lvd_conv_halo_eligible(const lvd_gemm_params* p) {
   if (p->a2 != nullptr || p->cin % 32 != 0 || p->c1 < p->cin || p->cin < 32) return false;
   if ((long)p->M * p->lda1 >= (1L << 30) || (long)p->N * p->K >= (1L << 30)) return false;
   if (p->mode == LVD_A_CONV3X3)
-    return p->stride == 1 && p->upsample == 0 && p->hin == p->hout && p->win == p->wout && p->win <= 87;
+    return p->stride == 1 && p->hin == p->hout && p->win == p->wout && p->win <= 87 && (!p->upsample || (p->hin % 2 == 0 && p->win % 2 == 0));
   if (p->mode == LVD_A_TCONV3) return p->frames >= 2 && p->frames <= 256 && p->m_begin == 0 && p->M % (p->frames * p->hw) == 0;
   return false;
 }

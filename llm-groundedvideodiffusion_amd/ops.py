@@ -95,7 +95,7 @@ def _tune_gemm(p, key, out):
     p.out, p.accumulate = scratch.data_ptr(), 0
     best, best_t = 0, float("inf")
     cands = GEMM_CANDIDATES + ((SPLITK_VARIANT, SPLITK_WIDE_VARIANT) + TAIL_VARIANTS if p.ws else ())
-    halo = (p.mode == A_CONV3X3 and p.stride == 1 and not p.upsample and p.win <= 87) or (p.mode == A_TCONV3 and 2 <= p.frames <= 256)
+    halo = (p.mode == A_CONV3X3 and p.stride == 1 and p.win <= 87) or (p.mode == A_TCONV3 and 2 <= p.frames <= 256)
     if halo and not p.a2 and p.cin % 32 == 0:
         cands += (HALO_VARIANTS if p.ws else HALO_VARIANTS[:1])  # LDS-resident im2col (conv_halo.hip)
     for v in cands:

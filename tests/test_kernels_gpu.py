@@ -456,6 +456,12 @@ def test_conv_halo(variant, n, cin, cout, h, wd):
     out2 = ops.gemm(bf(to_tokens(x)), pack_conv(wt), bias=b, rowbias=rowb, rows_per_sample=h * wd, res=res, alpha=0.5, mode=ops.A_CONV3X3,
                     conv=ops.ConvGeom(h, wd, h, wd), variant=variant)
     assert torch.equal(out, out2), "halo conv must be deterministic"
+    if h % 1 == 0:  # fused nearest-x2 upsample: the source is stored at (h, wd), the conv runs at (2h, 2wd)
+        if 2 * wd <= 87:
+            xu = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            refu = to_tokens(F.conv2d(xu, wt, b, padding=1))
+            outu = ops.gemm(bf(to_tokens(x)), pack_conv(wt), bias=b, mode=ops.A_CONV3X3, conv=ops.ConvGeom(2 * h, 2 * wd, 2 * h, 2 * wd, 1, 1), variant=variant)
+            close(outu, refu, 6e-3, f"v{variant} halo conv with fused upsample")
     from lvd_amd.weights import pack_conv3x3_dgrad
     xg = x.clone().requires_grad_(True)
     y = F.conv2d(xg, wt, None, padding=1)
