@@ -52,19 +52,20 @@ def demo_layout():
 
 
 class GemmTimer:
-    """HIP-event timing of the dominant kernel class (MFMA GEMM with the linear loader: ~750 of the ~1130 GEMM launches
-    and the largest share of a guided step) over the timed region.  Events are recorded on torch's current stream, which
-    is the stream the kernels are launched on.  An event pair is a barrier packet on each side of the launch (~3 us of
-    idle GPU each, measured in the rocprof trace: 6 % of the step when every launch is bracketed), so every `stride`-th
-    launch of the class is bracketed; a step has 753 such launches (753 % 8 == 1), so the sampled positions rotate by one
-    every step and 8 timed steps cover every launch site exactly once."""
+    """HIP-event timing of every MFMA GEMM class (linear loader, 3x3 conv, temporal conv, transposed conv) over the timed
+    region; the dominant class is the one with the most time.  Events are recorded on torch's current stream, which is the
+    stream the kernels are launched on.  An event pair is a barrier packet on each side of the launch (~3 us of idle GPU
+    each, measured in the rocprof trace: 6 % of the step when every launch is bracketed), so every `stride`-th GEMM launch
+    is bracketed; a step has 1133 GEMM launches (1133 % 8 == 5, coprime with 8), so the sampled positions rotate every step
+    and 8 timed steps cover every launch site exactly once."""
 
-    def __init__(self, modes=(ops.A_PLAIN,), stride=8):
+    def __init__(self, modes=(ops.A_PLAIN, ops.A_CONV3X3, ops.A_TCONV3, ops.A_CONV3X3_T2), stride=8):
         self.rec = []
         self.orig = ops.gemm
         self.modes = modes
         self.stride = stride
         self.count = 0
+        self.per_mode = {}
 
     def __enter__(self):
         def timed(a1, w, **kw):
@@ -72,6 +73,7 @@ class GemmTimer:
             if mode not in self.modes:
                 return self.orig(a1, w, **kw)
             self.count += 1
+            self.per_mode[mode] = self.per_mode.get(mode, 0) + 1
             if self.count % self.stride:
                 return self.orig(a1, w, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,30 +100,86 @@ class GemmTimer:
         return agg
 
 
-def cpu_baseline(sd_cpu, cfg):
-    """fp32 oracle (restatement of the reference) on the host cores: ONE CFG forward at BASELINE config 1
-    (256x144x8, latent 18x32) = 2.87 TFLOP, extrapolated to the guided Zeroscope step by algorithmic FLOPs."""
-    from oracle import unet_ref
+def cpu_baseline(sd_cpu, cfg, budget_s=45.0):
+    """fp32 oracle (restatement of the reference, oracle/) on the host cores, three bounded legs:
+      A. BASELINE config 0 end to end: 256x144x8 (latent 18x32), DPM-Solver++ CFG sampling loop, 10 steps (stops early when
+         the leg's time budget is spent; the steps are identical work, the per-step time is what is reported);
+      B. ONE CFG UNet forward at the largest of (8x18x32, 12x24x40, 16x32x32, 24x40x72) predicted to fit the budget;
+      C. ONE guidance iteration (cond-branch forward with saved attention maps + compute_ca_loss + autograd backward to the
+         latents) at the largest size predicted to fit the budget — a different FLOP/s regime than a forward.
+    `value` extrapolates the guided 576x320x24 step from B (CFG forward part) and C (guidance part) by algorithmic FLOPs,
+    each leg with its own measured rate; every extrapolation factor is spelled out in `sample`."""
+    from oracle import guidance_ref, scheduler_ref, unet_ref
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, 8, 18, 32, generator=g)
-    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     cores = torch.get_num_threads()
+    fl_per_cell = TF_CFG_FWD / (2 * FRAMES * LAT_H * LAT_W)       # TFLOP per (batch item, frame, latent pixel) of a forward
+    gfl_per_cell = TF_GUIDANCE_ITER / (FRAMES * LAT_H * LAT_W)    # guidance iteration (fwd to the last key + backward), B=1
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+
+    # ---- A: config 0 loop
+    sch = scheduler_ref.DPMSolverPP2M()
+    sch.set_timesteps(10)
+    lat = torch.randn(1, 4, 8, 18, 32, generator=g)
+    t0 = time.time()
+    done = 0
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps):
+            eps = unet_ref.unet_forward(sd_cpu, cfg, lat.expand(2, -1, -1, -1, -1), int(t), ehs)
+            lat = sch.step(eps[0:1] + 9.0 * (eps[1:2] - eps[0:1]), lat)
+            done += 1
+            if time.time() - t0 > budget_s:
+                break
+    t_a = (time.time() - t0) / done
+    tf_a = 2 * 8 * 18 * 32 * fl_per_cell
+    rate_fwd = tf_a / t_a
+
+    # ---- B: one CFG forward at the largest size that fits the budget
+    sizes = [(8, 18, 32), (12, 24, 40), (16, 32, 32), (24, 40, 72)]
+    fit = [z for z in sizes if 2 * z[0] * z[1] * z[2] * fl_per_cell / rate_fwd <= budget_s] or sizes[:1]
+    fb = fit[-1]
+    x = torch.randn(2, 4, *fb, generator=g)
     with torch.no_grad():
         t0 = time.time()
         unet_ref.unet_forward(sd_cpu, cfg, x, 500, ehs)
-        dt = time.time() - t0
-    tf_sample = 2.87
-    tflops = tf_sample / dt
-    t_guided = (TF_CFG_FWD + TF_GUIDANCE_ITER) / tflops
+        t_b = time.time() - t0
+    tf_b = 2 * fb[0] * fb[1] * fb[2] * fl_per_cell
+    rate_b = tf_b / t_b
+
+    # ---- C: one guidance iteration (autograd through the oracle)
+    sizes_c = [(8, 16, 32), (12, 24, 40), (16, 32, 32), (24, 40, 72)]  # latent H, W divisible by 8 (the reference's attention-map geometry, utils/guidance.py)
+    fitc = [z for z in sizes_c if z[0] * z[1] * z[2] * gfl_per_cell / (0.6 * rate_fwd) <= budget_s] or sizes_c[:1]
+    fc = fitc[-1]
+    bboxes, positions = demo_layout()
+    bboxes = [bx[:fc[0]] for bx in bboxes]
+    latc = torch.randn(1, 4, *fc, generator=g)
+
+    def unet_fn(xx, tt, cond, save, save_keys):
+        unet_ref.unet_forward(sd_cpu, cfg, xx, int(tt), cond, save_attn_to_dict=save, save_keys=save_keys, stop_after_key=GUIDANCE_KEYS[-1])
+
+    t0 = time.time()
+    guidance_ref.latent_backward_guidance(unet_fn, sch.alphas_cumprod, ehs[1:2], 0, bboxes, positions, 500, latc, 10000.0, loss_scale=2.5,
+                                          loss_threshold=0.0, max_iter=1, max_index_step=10, guidance_attn_keys=GUIDANCE_KEYS,
+                                          base_attn_dim=(fc[1], fc[2]), fg_top_p=0.25, bg_top_p=0.25, fg_weight=1.0, bg_weight=2.0)
+    t_c = time.time() - t0
+    tf_c = fc[0] * fc[1] * fc[2] * gfl_per_cell
+    rate_c = tf_c / t_c
+
+    t_guided = TF_CFG_FWD / rate_b + TF_GUIDANCE_ITER / rate_c
     return {"value": round(FRAMES / t_guided, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"one fp32 CFG UNet forward at 256x144x8 (2.87 TFLOP) took {dt:.1f}s = {tflops:.3f} TFLOP/s; "
-                      f"extrapolated by FLOPs to the guided 576x320x24 step ({TF_CFG_FWD + TF_GUIDANCE_ITER:.1f} TFLOP)"}
+            "legs": {"config0_loop": {"steps_run": done, "of": 10, "s_per_step": round(t_a, 2), "tflops": round(rate_fwd, 3),
+                                      "frames_per_s": round(8 / t_a, 3), "workload": "256x144x8, CFG DPM-Solver++ step, fp32"},
+                     "cfg_forward": {"frames_h_w": list(fb), "s": round(t_b, 2), "tflop": round(tf_b, 2), "tflops": round(rate_b, 3)},
+                     "guidance_iteration": {"frames_h_w": list(fc), "s": round(t_c, 2), "tflop": round(tf_c, 2), "tflops": round(rate_c, 3)}},
+            "sample": f"fp32 oracle on {cores} threads: (A) config 0 loop 256x144x8: {done}/10 CFG steps, {t_a:.1f} s/step = {rate_fwd:.3f} TFLOP/s; "
+                      f"(B) one CFG forward at {fb[0]}x{fb[1]}x{fb[2]} latents ({tf_b:.2f} TFLOP) {t_b:.1f} s = {rate_b:.3f} TFLOP/s; "
+                      f"(C) one guidance iteration with autograd at {fc[0]}x{fc[1]}x{fc[2]} ({tf_c:.2f} TFLOP) {t_c:.1f} s = {rate_c:.3f} TFLOP/s; "
+                      f"guided 576x320x24 step extrapolated by algorithmic FLOPs: {TF_CFG_FWD}/{rate_b:.3f} + {TF_GUIDANCE_ITER}/{rate_c:.3f} s = {t_guided:.0f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unguided-steps", type=int, default=4, help="extra (untimed-for-value) unguided steps for the breakdown")
@@ -166,7 +224,7 @@ def main():
         gb[FRAMES:, :len(bboxes)] = torch.tensor(bboxes).permute(1, 0, 2)
         gm[FRAMES:, :len(bboxes)] = 1.0
         gligen = {"boxes": gb, "masks": gm, "positive_embeddings": torch.randn(2 * FRAMES, 30, cfg.cross_attention_dim, device=dev, generator=g).cpu()}
-    sched = DPMSolverPP2MSchedule()
+    sched = DPMSolverPP2MSchedule.from_ddim_config()  # the reference's effective schedule: t = 961, 937, ..., 25
     sched.set_timesteps(40)
     sampler = HipSampler(engine, sched, guidance_scale=9.0)
     sampler.reset(latents)
@@ -211,18 +269,24 @@ def main():
     # timed region: exactly K guided steps; every 8th launch of the dominant GEMM class is bracketed by HIP events on the
     # launch stream (GemmTimer; no extra synchronisation)
     gt = GemmTimer()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # step boundaries on the launch stream
     sync()
     t0 = time.perf_counter()
     with gt:
-        for _ in range(args.steps):
+        marks[0].record()
+        for k in range(args.steps):
             last_loss = guided_step()
+            marks[k + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    med = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if dist is not None:
-        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([dt, med], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_guided = dt / args.steps * 1e3
+        dt, med = float(tt[0].item()), float(tt[1].item())
+    ms_mean = dt / args.steps * 1e3   # wall clock of the K steps (barrier + synchronize on both sides), max over ranks
+    ms_guided = med                   # median of the K per-step times (HIP events at the step boundaries), max over ranks
     finite = bool(torch.isfinite(last_loss).all())
     keep_finite()
 
@@ -240,19 +304,30 @@ def main():
     roof = None
     if rank == 0:
         agg = gt.summary()
-        names = {ops.A_PLAIN: "MFMA GEMM, linear loader (gemm.hip / gemm_ring.hip)", ops.A_CONV3X3: "MFMA GEMM, implicit 3x3 conv loader",
-                 ops.A_TCONV3: "MFMA GEMM, temporal 3-tap loader", ops.A_CONV3X3_T2: "MFMA GEMM, transposed stride-2 conv loader"}
+        names = {ops.A_PLAIN: "MFMA GEMM, linear loader (gemm_ring.hip asm-DMA ring / gemm.hip)",
+                 ops.A_CONV3X3: "MFMA tap GEMM, 3x3 conv with the im2col tile resident in LDS (conv_halo.hip; stride-2 / odd shapes: gemm_ring.hip)",
+                 ops.A_TCONV3: "MFMA tap GEMM, temporal (3,1,1) conv, tile resident in LDS (conv_halo.hip)",
+                 ops.A_CONV3X3_T2: "MFMA GEMM, transposed stride-2 conv loader (gemm_ring.hip)"}
+        keyname = {ops.A_PLAIN: "linear", ops.A_CONV3X3: "conv3x3", ops.A_TCONV3: "tconv3", ops.A_CONV3X3_T2: "conv3x3_t2"}
         dom = max(agg, key=lambda m: agg[m][1])
         n, secs, fl = agg[dom]
         ach = fl / secs / 1e12
+        traffic, tnote = None, "no profiles/r02_gemm_traffic.json next to bench.py"
+        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        if os.path.exists(tpath):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py, rolled up by tools/pmc_traffic.py
+            tj = json.load(open(tpath)).get(keyname[dom])
+            if tj:
+                traffic = {"hbm_side_bytes_per_launch": tj["fetch_bytes"] + tj["write_bytes"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes"],
+                           "ratio": round((tj["fetch_bytes"] + tj["write_bytes"]) / tj["algorithmic_bytes"], 3), "shape": tj["shape"]}
+                tnote = tj.get("note", "")
         roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "traffic_note": "not collected live (needs rocprofv3 --pmc); per-shape FETCH_SIZE/WRITE_SIZE of this kernel class: profiles/r01_gemm_pmc_traffic.txt "
-                                "(e.g. M=138240 N=960 K=320: 113 MB fetched vs 89 MB algorithmic, 240 MB written vs 265 MB)",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                 "launches": n, "sampled_every": gt.stride,
-                "class_launches_in_timed_region": gt.count, "avg_launch_us": round(secs / n * 1e6, 1),
+                "class_launches_in_timed_region": gt.per_mode.get(dom, 0), "avg_launch_us": round(secs / n * 1e6, 1),
                 "flops_per_launch": round(fl / n / 1e9, 2), "flops_per_launch_unit": "GFLOP",
-                "all_gemm": {names[m]: {"launches": v[0], "ms_per_step": round(v[1] * 1e3 * gt.stride / args.steps, 2), "tflops": round(v[2] / v[1] / 1e12, 1)} for m, v in agg.items()}}
+                "all_gemm": {keyname[m]: {"kernel": names[m], "launches_sampled": v[0], "launches_per_step": round(gt.per_mode.get(m, 0) / args.steps, 1),
+                                          "ms_per_step": round(v[1] * 1e3 * gt.stride / args.steps, 2), "tflops": round(v[2] / v[1] / 1e12, 1),
+                                          "frac": round(v[2] / v[1] / 1e12 / PEAK_BF16_TFLOPS, 4)} for m, v in agg.items()}}
 
     cpu = None
     if sd_cpu is not None:
@@ -266,7 +341,8 @@ def main():
         out = {
             "metric": "denoise-step frames/sec, LVD-Zeroscope 576x320x24 w/ guidance" + (" + GLIGEN adapters" if args.gligen else ""),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_guided, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_guided, 2), "ms_per_step_stat": "median of the K per-step times (HIP events on the launch stream)",
+            "mean_ms_per_step": round(ms_mean, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "lvd_zeroscope 576x320x24 (latent 40x72, 24 frames), guided step: 1 guidance iteration over 6 keys "
                                    "+ CFG UNet forward (B=2) + DPM-Solver++ update; random-init zeroscope-topology weights (1411M params)"

@@ -61,15 +61,21 @@ def main(argv=None):
     baseline = run_model in ("modelscope", "zeroscope", "modelscope_256")
     option = run_model.split("_")[1] if "_" in run_model else ""
     run = None
+    dist = None
     if not args.dry_run:
         import torch
         import lvd_amd  # noqa: F401
         from lvd_amd.generation import _common
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)  # kernels launch on the CURRENT device's stream: one process per GPU must select its own
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(os.environ.get("LVD_DIST_BACKEND", "nccl"))  # RCCL; only the end-of-run tally uses it
         if args.synthetic_weights:
             _common.configure(state_dict="synthetic")
         elif args.checkpoint:
             _common.configure(state_dict=torch.load(args.checkpoint, map_location="cpu"))
-        _common.configure(device=f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        _common.configure(device=f"cuda:{local_rank}")
         modname = {"lvd-plus": "lvd_plus", "lvd-gligen": "lvd_gligen", "lvd": "lvd", "modelscope": "modelscope_dpm", "zeroscope": "zeroscope_dpm"}[run_model.split("_")[0]]
         generation = importlib.import_module(f"lvd_amd.generation.{modname}")
         H, W = generation.init(option) if baseline else generation.init(base_model=option if option else "modelscope512")
@@ -78,11 +84,11 @@ def main(argv=None):
         assert generation.version == run_model.split("_")[0], f"{generation.version} != {run_model.split('_')[0]}"
         run = generation.run
 
-    from lvd_amd import dsl
+    from lvd_amd import dsl, sharding
     model = MODEL_NAMES[args.model]
     cache = None
     if not baseline:
-        cache = dsl.LayoutCache(os.path.join(args.cache_dir, f"cache_{args.prompt_type}_{args.template_version}_{model}.json"))
+        cache = dsl.LayoutCache(os.path.join(args.cache_dir, f"cache_{args.prompt_type.replace('lmd_', '')}_{args.template_version}_{model}.json"))
     if args.prompt_type == "demo":
         prompts = PROMPTS_DEMO
     elif args.prompt_type.startswith("lvd") and not args.prompts_file:
@@ -95,7 +101,8 @@ def main(argv=None):
     run_kwargs = {k: getattr(args, k) for k in ["fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "loss_threshold", "loss_scale", "boxdiff_loss_scale",
                                                  "com_loss_scale", "gligen_scheduled_sampling_beta", "num_inference_steps", "max_iter", "max_index_step",
                                                  "num_frames", "use_ratio_based_loss", "boxdiff_normed"] if getattr(args, k) is not None}
-    base_save = f"{args.img_root}/imgs_{args.prompt_type}_template{args.template_version}_{run_model}" + (f"_{args.save_suffix}" if args.save_suffix else "")
+    model_in_base_save_dir = "" if model == "gpt-4" else f"_{model}"  # same directory names as the reference (generate.py:207-208): its eval scripts find them
+    base_save = f"{args.img_root}/imgs_{args.prompt_type}_template{args.template_version}{model_in_base_save_dir}_{run_model}" + (f"_{args.save_suffix}" if args.save_suffix else "")
     if args.force_run_ind is not None:
         run_ind = args.force_run_ind
     else:
@@ -110,10 +117,12 @@ def main(argv=None):
         if cache:
             cache.reset_access()
         for prompt_ind, prompt in enumerate(prompts):
-            skip = prompt_ind < args.skip_first_prompts or (args.num_prompts is not None and prompt_ind >= args.skip_first_prompts + args.num_prompts)
+            if prompt_ind < args.skip_first_prompts or (args.num_prompts is not None and prompt_ind >= args.skip_first_prompts + args.num_prompts):
+                ind += 1  # outside the requested range: the cache entry is NOT consumed (reference generate.py:255-262)
+                continue
             prompt = prompt.strip().rstrip(".")
             resp = None if baseline else cache.get(prompt)  # every rank walks the cache identically (sequential semantics)
-            if skip or ind % world != rank:
+            if not sharding.owns(ind, rank, world):
                 ind += 1
                 continue
             if not baseline and resp is None:
@@ -149,6 +158,13 @@ def main(argv=None):
                     raise
             ind += 1
     print(f"rank {rank}: generated {generated} video(s)")
+    if dist is not None:  # end-of-run tally over RCCL (the only collective: every rank wrote its own directory entries)
+        import torch
+        tot = torch.tensor([generated], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tot)
+        if rank == 0:
+            print(f"all ranks: generated {int(tot.item())} video(s)")
+        dist.destroy_process_group()
     return generated
 
 

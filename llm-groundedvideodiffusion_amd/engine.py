@@ -97,7 +97,7 @@ class TextCache:
 class HipUNet3D:
     def __init__(self, cfg: UNetConfig, state_dict, device="cuda"):
         self.cfg = cfg
-        self.dev = torch.device(device)
+        self.dev = ops.use_device(device)
         self.w = {}
         self.alpha = {}
         self._dgrad = {}
@@ -464,6 +464,7 @@ class HipUNet3D:
         Returns None when stopped early.
         """
         cfg = self.cfg
+        ops.use_device(self.dev)
         boc = cfg.block_out_channels
         dh = cfg.attention_head_dim
         assert dh == 64, "kernels are specialised for attention_head_dim 64"

@@ -70,7 +70,7 @@ class Method:
         if isinstance(text_encoder, dict):
             from ..text_encoder import CLIPTextConfig, HipCLIPTextEncoder
             text_encoder = HipCLIPTextEncoder(CLIPTextConfig(**(_components["text_encoder_config"] or {})), text_encoder, device=_components["device"])
-        self.pipe = TextToVideoSDPipeline(unet=unet, scheduler=DPMSolverPP2MSchedule(), vae=vae,
+        self.pipe = TextToVideoSDPipeline(unet=unet, scheduler=DPMSolverPP2MSchedule.from_ddim_config(), vae=vae,
                                           text_encoder=text_encoder, tokenizer=_components["tokenizer"]).to(_components["device"])
         self.pipe.guidance_models = None
         return self.base["H"], self.base["W"]

@@ -63,16 +63,41 @@ class GuidanceLayout:
                 tok_w.append(1.0 / len(positions))
         self.nobj, self.ntok, self.H, self.W = nobj, len(tok_ids), H, W
         self.boxes = torch.from_numpy(arr).to(device)
+        self.tok_ids_host = np.asarray(tok_ids, dtype=np.int64)
         self.tok_ids = torch.tensor(tok_ids, dtype=torch.int32, device=device)
         self.tok_obj = torch.tensor(tok_obj, dtype=torch.int32, device=device)
         self.tok_weight = torch.tensor(tok_w, dtype=torch.float32, device=device)
+
+    def token_slice(self, a, b):
+        """The same boxes with object tokens [a, b) only (views: nothing is copied)."""
+        sub = object.__new__(GuidanceLayout)
+        sub.nobj, sub.ntok, sub.H, sub.W, sub.boxes = self.nobj, b - a, self.H, self.W, self.boxes
+        sub.tok_ids_host, sub.tok_ids, sub.tok_obj, sub.tok_weight = self.tok_ids_host[a:b], self.tok_ids[a:b], self.tok_obj[a:b], self.tok_weight[a:b]
+        return sub
+
+
+MAX_TOKENS_PER_LAUNCH = 16  # csrc/guidance_loss.hip MAXTOK: object-token columns one launch keeps per query
 
 
 def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext, grad_scale, fg_weight, bg_weight,
                           com_loss_scale, loss_partial, want_dq=True):
     """One guidance key: q [frames*P, heads*64] bf16, k [ntext, heads*64] bf16 (strided ok).
 
-    Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ."""
+    Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ.  Layouts with
+    more object tokens than one launch holds run in chunks of tokens: the loss terms are per token and dQ is linear in them."""
+    if layout.ntok and int(layout.tok_ids_host.max()) >= ntext:  # the reference indexes attn[..., pos] and raises the same way
+        raise IndexError(f"object token position {int(layout.tok_ids_host.max())} is out of bounds for {ntext} text tokens")
+    if layout.ntok > MAX_TOKENS_PER_LAUNCH:
+        dq_total, off = None, 0
+        for c0 in range(0, layout.ntok, MAX_TOKENS_PER_LAUNCH):
+            sub = layout.token_slice(c0, min(layout.ntok, c0 + MAX_TOKENS_PER_LAUNCH))
+            n = frames * heads * sub.ntok
+            dq = ca_energy_loss_and_dq(q, k, heads, frames, sub, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                       com_loss_scale=com_loss_scale, loss_partial=loss_partial[off:off + n], want_dq=want_dq)
+            off += n
+            if want_dq:
+                dq_total = dq if dq_total is None else ops.add(dq_total, dq, out=dq_total)
+        return dq_total
     dev = q.device
     P = layout.H * layout.W
     assert q.shape[0] == frames * P, (q.shape, frames, P)

@@ -27,7 +27,7 @@ class TextToVideoSDPipelineOutput:
 class TextToVideoSDPipeline:
     def __init__(self, unet, scheduler=None, vae=None, text_encoder=None, tokenizer=None, vae_scale_factor=8):
         self.unet = unet
-        self.scheduler = scheduler if scheduler is not None else DPMSolverPP2MSchedule()
+        self.scheduler = scheduler if scheduler is not None else DPMSolverPP2MSchedule.from_ddim_config()
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
         self.vae_scale_factor = vae_scale_factor
         self.guidance_models = None

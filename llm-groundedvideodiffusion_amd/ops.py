@@ -25,6 +25,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def use_device(dev):
+    """Make `dev` the CURRENT HIP device of this process.  The C ABI launches on the stream it is handed and hipLaunchKernelGGL
+    targets the current device, so an engine built on cuda:N must run with device N current — one process per GPU selects its own
+    (generate.py, scripts/*, bench.py under torchrun).  Called by every engine constructor and forward entry; a no-op when already set."""
+    dev = torch.device(dev)
+    if dev.type == "cuda":
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if torch.cuda.current_device() != idx:
+            torch.cuda.set_device(idx)
+    return dev
+
+
 def _ld(t):
     assert t.dim() == 2 and t.stride(1) == 1, f"expected row-major 2-D tensor, got {tuple(t.shape)} / {t.stride()}"
     return t.stride(0)

@@ -17,8 +17,16 @@ from . import ops
 
 
 class DPMSolverPP2MSchedule:
+    """Constructor defaults = the diffusers class defaults (linspace spacing).  The reference never uses those: it builds
+    `DPMSolverMultistepScheduler.from_config(pipe.scheduler.config)` (generation/lvd.py:46) from the checkpoint's DDIMScheduler,
+    whose registered config carries DDIM's `timestep_spacing="leading"` and the checkpoint's `steps_offset=1`; that is
+    `from_ddim_config()` below, and what every generation method here uses: 40 steps -> t = 961, 937, ..., 25."""
     order = 1  # pipeline bookkeeping (`scheduler.order`): one model evaluation per step
     init_noise_sigma = 1.0
+
+    @classmethod
+    def from_ddim_config(cls, **kw):
+        return cls(**{"timestep_spacing": "leading", "steps_offset": 1, **kw})
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, timestep_spacing="linspace", steps_offset=0):
         betas = np.linspace(beta_start**0.5, beta_end**0.5, num_train_timesteps, dtype=np.float32).astype(np.float64) ** 2

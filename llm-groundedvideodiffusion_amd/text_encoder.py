@@ -79,7 +79,7 @@ class HipCLIPTextEncoder:
     def __init__(self, cfg: CLIPTextConfig, state_dict, device="cuda"):
         assert cfg.hidden_size % cfg.num_attention_heads == 0 and cfg.hidden_size // cfg.num_attention_heads == 64, "head_dim must be 64"
         assert cfg.hidden_act in ("gelu", "quick_gelu"), cfg.hidden_act
-        self.cfg, self.dev = cfg, torch.device(device)
+        self.cfg, self.dev = cfg, ops.use_device(device)
         sd = {(k[len("text_model."):] if k.startswith("text_model.") else k): v for k, v in state_dict.items()}
         bf = lambda t: t.to(self.dev, torch.bfloat16).contiguous()
         f32 = lambda t: t.to(self.dev, torch.float32).contiguous()

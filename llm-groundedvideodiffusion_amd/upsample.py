@@ -24,7 +24,7 @@ class HipVideoToVideo:
         """`encode_prompt(list_of_str) -> (n, 77, cross_dim)` embeddings (e.g. tokenizer + HipCLIPTextEncoder); only needed when
         the call passes strings instead of `prompt_embeds`."""
         self.unet, self.enc, self.dec = unet, vae_encoder, vae_decoder
-        self.schedule = schedule or DPMSolverPP2MSchedule()
+        self.schedule = schedule or DPMSolverPP2MSchedule.from_ddim_config()
         self.encode_prompt = encode_prompt
 
     @staticmethod

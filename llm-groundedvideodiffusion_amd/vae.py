@@ -86,7 +86,7 @@ class _VAEBlocks:
 
 class HipVAEDecoder(_VAEBlocks):
     def __init__(self, cfg: VAEConfig, state_dict, device="cuda"):
-        self.cfg, self.dev = cfg, torch.device(device)
+        self.cfg, self.dev = cfg, ops.use_device(device)
         self.w = _load_vae_weights(state_dict, self.dev, ("decoder.", "post_quant_conv."))
         # conv_out: 3 output channels -> 4 (GEMM N % 4), post_quant_conv: 4 -> 8 in and out (K % 8, token width of conv_in)
         wo, bo = self.w["decoder.conv_out.weight"], self.w["decoder.conv_out.bias"]
@@ -140,7 +140,7 @@ class HipVAEEncoder(_VAEBlocks):
     conv kernel family is untouched; the two rotations are row gathers on the token matrix."""
 
     def __init__(self, cfg: VAEConfig, state_dict, device="cuda"):
-        self.cfg, self.dev = cfg, torch.device(device)
+        self.cfg, self.dev = cfg, ops.use_device(device)
         self.w = _load_vae_weights(state_dict, self.dev, ("encoder.", "quant_conv."), flip_taps=(".downsamplers.",))
 
     def _downsample(self, x, name, n, h, w):

@@ -48,6 +48,14 @@ def load_detector(args, device):
     return HipOwlViTDetector(cfg, sd, device=device, tokenize=tokenize)
 
 
+def _local_device():
+    """cuda:<LOCAL_RANK>, made the current device (kernels launch on the current device's stream: one process per GPU)."""
+    import torch
+    idx = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(idx)
+    return f"cuda:{idx}"
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--prompt-type", type=str, default="lvd")
@@ -71,7 +79,7 @@ def main(argv=None):
     from lvd_amd.evaluation import ScoreBoard, get_prompts, score_video
     np.set_printoptions(precision=2)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    detector = load_detector(args, f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+    detector = load_detector(args, _local_device())
     pairs = get_prompts(args.prompt_type, return_predicates=True)
     print(f"Number of prompts (predicates): {len(pairs)}")
     print(f"Number of evaluating frames: {args.num_eval_frames}")

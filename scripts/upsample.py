@@ -45,6 +45,14 @@ def build(args, device):
                            HipVAEDecoder(vcfg, vae_sd, device=device), encode_prompt=encode_prompt)
 
 
+def _local_device():
+    """cuda:<LOCAL_RANK>, made the current device (kernels launch on the current device's stream: one process per GPU)."""
+    import torch
+    idx = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(idx)
+    return f"cuda:{idx}"
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--videos", nargs="+", required=True, type=str, help="path to videos in joblib format")
@@ -73,7 +81,7 @@ def main(argv=None):
     import torch
     import lvd_amd  # noqa: F401
     from lvd_amd import vis
-    pipe = build(args, f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+    pipe = build(args, _local_device())
     prompts = args.prompts * len(args.videos) if len(args.prompts) == 1 else args.prompts
     size = tuple(args.size) if args.size else ((576, 1024) if args.horizontal else (1024, 1024))
     written = []

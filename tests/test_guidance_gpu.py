@@ -105,6 +105,35 @@ def test_fused_loss_kernels_vs_oracle(com):
     assert rel(dq, gq) < 1.5e-2, rel(dq, gq)   # dq is stored in bf16
 
 
+def test_fused_loss_many_object_tokens_and_bounds():
+    """More object tokens than one launch keeps per query (csrc/guidance_loss.hip MAXTOK = 16) run in token chunks — loss and dQ
+    are per-token / linear in the tokens; a token position beyond the text length raises IndexError like the reference's indexing."""
+    frames, heads, Hh, Ww, nt = 2, 2, 8, 8, 77
+    P, C = Hh * Ww, heads * 64
+    q = rnd(frames * P, C, seed=1, scale=1.5).bfloat16()
+    k = rnd(nt, C, seed=2).bfloat16()
+    bboxes = [[[0.1, 0.2, 0.55, 0.8], [0.15, 0.2, 0.6, 0.8]], [[0.5, 0.5, 0.9, 0.95], [0.4, 0.45, 0.8, 0.9]]]
+    pos = [list(range(1, 13)), list(range(20, 29))]  # 12 + 9 = 21 tokens
+    hp = dict(fg_top_p=0.3, bg_top_p=0.4, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03)
+    qa = q.float().requires_grad_(True)
+    probs = (qa.reshape(frames, P, heads, 64).permute(0, 2, 1, 3) @ k.float().reshape(nt, heads, 64).permute(1, 2, 0)[None] * 0.125).softmax(-1)
+    ref = guidance_ref.compute_ca_loss({"k": probs}, bboxes, pos, ["k"], (Hh, Ww), **hp) * 5.0
+    (gq,) = torch.autograd.grad(ref, qa)
+    lay = guidance.GuidanceLayout(bboxes, pos, frames, Hh, Ww, hp["fg_top_p"], hp["bg_top_p"], DEV)
+    assert lay.ntok == 21 > guidance.MAX_TOKENS_PER_LAUNCH
+    partial = torch.zeros(frames * heads * lay.ntok, device=DEV)
+    gs = 5.0 / len(bboxes)
+    dq = guidance.ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=nt, grad_scale=gs, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03,
+                                        loss_partial=partial)
+    loss = ops.reduce_sum(partial, gs).item()
+    assert abs(loss - ref.item()) < 2e-4 * abs(ref.item()), (loss, ref.item())
+    assert rel(dq, gq) < 2e-2, rel(dq, gq)   # bf16 dq, two chunks added in bf16
+    bad = guidance.GuidanceLayout(bboxes, [[2], [77]], frames, Hh, Ww, 0.3, 0.4, DEV)
+    with pytest.raises(IndexError):
+        guidance.ca_energy_loss_and_dq(q, k, heads, frames, bad, ntext=nt, grad_scale=gs, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.0,
+                                       loss_partial=torch.zeros(frames * heads * 2, device=DEV))
+
+
 def test_guidance_step_vs_reference_golden():
     """Latents after latent_backward_guidance (1 and 2 iterations) vs the reference run (fp32 CPU).
     Tolerance: loss 2e-2 relative, latent update rel-L2 0.08 (bf16 trunk forward+backward vs fp32)."""

@@ -85,8 +85,25 @@ def test_pipeline_input_checks():
     pipe.enable_fuser(False)
 
 
-def test_schedule_coefficients_match_oracle_scheduler():
-    a, b = DPMSolverPP2MSchedule(), scheduler_ref.DPMSolverPP2M()
+def test_generation_schedule_is_the_ddim_config_one():
+    """generation/lvd.py:46 converts the checkpoint's DDIM scheduler: DDIM's registered timestep_spacing="leading" and the SD-family
+    steps_offset=1 travel with the config (diffusers 0.27.2 set_timesteps, 'leading' branch): 40 steps -> 961, 937, ..., 25."""
+    s = DPMSolverPP2MSchedule.from_ddim_config()
+    s.set_timesteps(40)
+    assert list(s.timesteps) == [961 - 24 * i for i in range(40)]
+    s.set_timesteps(50)
+    assert list(s.timesteps) == [951 - 19 * i for i in range(50)]
+    from lvd_amd.models.controllable_pipeline_text_to_video_synth import TextToVideoSDPipeline
+    sch = TextToVideoSDPipeline(unet=None).scheduler
+    assert (sch.timestep_spacing, sch.steps_offset) == ("leading", 1)
+    d = DPMSolverPP2MSchedule()  # the bare class keeps the diffusers class defaults
+    d.set_timesteps(40)
+    assert int(d.timesteps[0]) == 999 and int(d.timesteps[-1]) == 25
+
+
+@pytest.mark.parametrize("spacing", [dict(), dict(timestep_spacing="leading", steps_offset=1)])
+def test_schedule_coefficients_match_oracle_scheduler(spacing):
+    a, b = DPMSolverPP2MSchedule(**spacing), scheduler_ref.DPMSolverPP2M(**spacing)
     for spacing_steps in (10, 40):
         a.set_timesteps(spacing_steps)
         b.set_timesteps(spacing_steps)

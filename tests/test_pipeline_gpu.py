@@ -84,7 +84,7 @@ def test_pipeline_guided_sampling_vs_oracle_loop():
                guidance_scale=9.0, latents=lat0.clone(), output_type="latent", backward_guidance_kwargs=bg,
                custom_latent_backward_guidance=hip_latent_backward_guidance).frames
     # oracle loop
-    sch = scheduler_ref.DPMSolverPP2M()
+    sch = scheduler_ref.DPMSolverPP2M(timestep_spacing="leading", steps_offset=1)
     sch.set_timesteps(4)
     lat, loss = lat0.clone(), 10000.0
     both = torch.cat([ne, pe])

@@ -51,7 +51,7 @@ def test_video_to_video_vs_oracle_loop(scale, tol_lat, tol_img):
     eps, noise = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
     big = np.stack([np.asarray(Image.fromarray(f).resize(size[::-1], Image.LANCZOS)) for f in video])
     z0 = vae_ref.encode_video(vsd, vcfg, big, eps)
-    sch = scheduler_ref.DPMSolverPP2M()
+    sch = scheduler_ref.DPMSolverPP2M(timestep_spacing="leading", steps_offset=1)
     sch.set_timesteps(steps)
     t_start = steps - min(int(steps * strength), steps)
     x = sch.add_noise(z0, noise.permute(1, 0, 2, 3).unsqueeze(0), t_start)
