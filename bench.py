@@ -329,6 +329,23 @@ def main():
                                           "ms_per_step": round(v[1] * 1e3 * gt.stride / args.steps, 2), "tflops": round(v[2] / v[1] / 1e12, 1),
                                           "frac": round(v[2] / v[1] / 1e12 / PEAK_BF16_TFLOPS, 4)} for m, v in agg.items()}}
 
+    # The one collective of the product: all_gather of decoded uint8 frames over RCCL, once per finished video in a
+    # harness that wants every video on rank 0.  Run it once here, untimed (not part of `value`), with a tensor of the decoded
+    # size (24x320x576x3 = 13.3 MB per rank) derived from this rank's latents, so the N > 1 runs really cross xGMI.
+    gather_ms = None
+    if dist is not None:
+        from lvd_amd.sharding import gather_frames
+        vid = (latents[0, :3].permute(1, 2, 3, 0).clamp(-1, 1).add(1).mul(127.5)).to(torch.uint8)             # (F, h, w, 3)
+        vid = vid.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()                                 # (F, 320, 576, 3)
+        if backend != "nccl":
+            vid = vid.cpu()
+        sync()
+        t0 = time.perf_counter()
+        allv = gather_frames(vid)
+        sync()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        assert len(allv) == world and allv[rank].shape == vid.shape and bool((allv[rank] == vid).all())
+
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, cfg)
@@ -356,6 +373,7 @@ def main():
             "step_mfma_frac": round(step_tf / (ms_guided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "unguided_mfma_frac": round(tf_cfg / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "loss_finite": finite,
+            "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

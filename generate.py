@@ -40,6 +40,8 @@ def build_parser():
     p.add_argument("--prompt-type", type=str, default="demo")
     p.add_argument("--template_version", choices=["v0.1"], required=True)
     p.add_argument("--dry-run", action="store_true", help="skip the generation")
+    p.add_argument("--gemm_autotune_table", default=None, help="JSON of per-shape GEMM tile-geometry choices: loaded if it exists (every rank / run "
+                   "then uses the same summation order: bit-identical videos for the same prompt and seed), written by rank 0 otherwise")
     for a in ["fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "loss_threshold", "loss_scale", "boxdiff_loss_scale", "com_loss_scale",
               "gligen_scheduled_sampling_beta"]:
         p.add_argument("--" + a, default=None, type=float)
@@ -71,6 +73,9 @@ def main(argv=None):
         if world > 1:
             import torch.distributed as dist
             dist.init_process_group(os.environ.get("LVD_DIST_BACKEND", "nccl"))  # RCCL; only the end-of-run tally uses it
+        if args.gemm_autotune_table and os.path.exists(args.gemm_autotune_table):
+            from lvd_amd import ops
+            ops.load_gemm_autotune_table(args.gemm_autotune_table)  # same tile geometry per shape in every rank / run
         if args.synthetic_weights:
             _common.configure(state_dict="synthetic")
         elif args.checkpoint:
@@ -101,7 +106,8 @@ def main(argv=None):
     run_kwargs = {k: getattr(args, k) for k in ["fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "loss_threshold", "loss_scale", "boxdiff_loss_scale",
                                                  "com_loss_scale", "gligen_scheduled_sampling_beta", "num_inference_steps", "max_iter", "max_index_step",
                                                  "num_frames", "use_ratio_based_loss", "boxdiff_normed"] if getattr(args, k) is not None}
-    model_in_base_save_dir = "" if model == "gpt-4" else f"_{model}"  # same directory names as the reference (generate.py:207-208): its eval scripts find them
+    # same directory names as the reference (generate.py:207-208: no suffix for --model gpt-4), so its eval scripts find them
+    model_in_base_save_dir = "" if args.model == "gpt-4" else f"_{model}"
     base_save = f"{args.img_root}/imgs_{args.prompt_type}_template{args.template_version}{model_in_base_save_dir}_{run_model}" + (f"_{args.save_suffix}" if args.save_suffix else "")
     if args.force_run_ind is not None:
         run_ind = args.force_run_ind
@@ -158,6 +164,9 @@ def main(argv=None):
                     raise
             ind += 1
     print(f"rank {rank}: generated {generated} video(s)")
+    if not args.dry_run and args.gemm_autotune_table and rank == 0 and not os.path.exists(args.gemm_autotune_table):
+        from lvd_amd import ops
+        ops.save_gemm_autotune_table(args.gemm_autotune_table)
     if dist is not None:  # end-of-run tally over RCCL (the only collective: every rank wrote its own directory entries)
         import torch
         tot = torch.tensor([generated], device="cuda" if dist.get_backend() == "nccl" else "cpu")

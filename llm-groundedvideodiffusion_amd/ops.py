@@ -97,6 +97,23 @@ def gemm_autotune_table():
     return dict(_gemm_choice)
 
 
+def save_gemm_autotune_table(path):
+    """Persist the per-shape geometry choices.  Variants differ in fp32 summation order (K-split slices, tile K order), so two
+    processes that tuned independently can produce different bf16 roundings for the same (prompt, seed); loading one table in
+    every rank / run (generate.py --gemm_autotune_table) makes sharded runs reproduce the single-process one bit for bit."""
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), v] for k, v in _gemm_choice.items()], f)
+
+
+def load_gemm_autotune_table(path):
+    import json
+    with open(path) as f:
+        for k, v in json.load(f):
+            k[7] = tuple(k[7]) if k[7] is not None else None
+            _gemm_choice[tuple(k)] = int(v)
+
+
 def _launch_gemm(p):
     hip.check(hip.lib().lvdhip_gemm(C.byref(p), _stream()), "gemm")
 

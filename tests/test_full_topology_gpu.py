@@ -68,3 +68,86 @@ def test_guidance_iteration_vs_oracle_autograd(full):
     print(f"full topology guidance: loss {float(loss):.4f} vs oracle {ref_loss:.4f}; update rel-L2 {rel(d, d_ref):.4f}")
     assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
     assert rel(d, d_ref) < 0.07  # measured 0.043
+
+
+def test_config3_modelscope_latents_cfg_forward_vs_oracle(full):
+    """BASELINE configs[3] geometry: 256x256x16 (latent 32x32, 16 frames) CFG forward of the full topology vs the fp32 oracle."""
+    cfg, net, sd = full
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 16, 32, 32, generator=gen)
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, cfg, x, 321, ehs)
+    out = net.forward(x.cuda(), 321, ehs.cuda())
+    e = rel(out, ref)
+    print("full topology, 256x256x16 CFG forward rel-L2 vs oracle:", e)
+    assert e < 3e-2
+
+
+@pytest.fixture(scope="module")
+def full_gated():
+    cfg = UNetConfig(attention_type="gated")
+    sd = synthetic_state_dict(cfg, seed=1, device="cuda")
+    return cfg, HipUNet3D(cfg, sd, device="cuda"), sd
+
+
+def _gligen_inputs(cfg, B, Fr, n_obj, gen):
+    """[uncond; cond] halves as the pipeline builds them (controllable_pipeline_text_to_video_synth.py:736-814)."""
+    boxes = torch.zeros(B * Fr, 30, 4)
+    masks = torch.zeros(B * Fr, 30)
+    emb = torch.zeros(B * Fr, 30, cfg.cross_attention_dim)
+    lo = torch.rand(Fr, n_obj, 2, generator=gen) * 0.5
+    bx = torch.cat([lo, lo + 0.1 + torch.rand(Fr, n_obj, 2, generator=gen) * 0.4], -1)
+    e = torch.randn(Fr, n_obj, cfg.cross_attention_dim, generator=gen)
+    for b in range(B):
+        boxes[b * Fr:(b + 1) * Fr, :n_obj] = bx
+        emb[b * Fr:(b + 1) * Fr, :n_obj] = e
+    masks[(B - 1) * Fr:, :n_obj] = 1.0  # only the cond half sees the objects
+    return {"boxes": boxes, "masks": masks, "positive_embeddings": emb}
+
+
+def test_gated_full_topology_vs_oracle_small_latent(full_gated):
+    """BASELINE configs[2] topology (1624 M parameters, GLIGEN fusers in every transformer block): CFG forward with the fusers on
+    vs the fp32 oracle at a latent the host finishes in seconds."""
+    cfg, net, sd = full_gated
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 4, 16, 24, generator=gen)
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen)
+    gl = _gligen_inputs(cfg, 2, 4, 3, gen)
+    sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd_cpu, cfg, x, 700, ehs, gligen=gl)
+        ref_off = unet_ref.unet_forward(sd_cpu, cfg, x, 700, ehs, gligen=gl, fuser_enabled=False)
+    out = net.forward(x.cuda(), 700, ehs.cuda(), gligen=gl)
+    out_off = net.forward(x.cuda(), 700, ehs.cuda(), gligen=gl, fuser_enabled=False)
+    print("gated full topology rel-L2 vs oracle: fusers on", rel(out, ref), "off", rel(out_off, ref_off), "on-vs-off", rel(ref, ref_off))
+    assert rel(out, ref) < 3e-2 and rel(out_off, ref_off) < 3e-2
+    assert rel(out, out_off) > 0.3 * rel(ref, ref_off) > 0  # the fusers act, and by about as much as in the oracle
+
+
+def test_gated_full_size_properties(full_gated):
+    """lvd-gligen at the headline size (576x320x24, latent 40x72: 2880 queries + 30 grounding keys per frame, PositionNet on
+    48 x 30 slots).  No oracle finishes here, so: (i) batch consistency — the cond half of the CFG batch equals a batch-1 run;
+    (ii) the fusers change the output; (iii) zero gates (alpha_attn = alpha_dense = 0) reproduce the fuser-off forward exactly."""
+    cfg, net, sd = full_gated
+    gen = torch.Generator().manual_seed(4)
+    Fr = 24
+    x = torch.randn(1, 4, Fr, 40, 72, generator=gen).cuda()
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen).cuda()
+    gl = _gligen_inputs(cfg, 2, Fr, 3, gen)
+    out2 = net.forward(x.expand(2, -1, -1, -1, -1).contiguous(), 500, ehs, gligen=gl)
+    gl1 = {k: v[Fr:] for k, v in gl.items()}
+    out1 = net.forward(x, 500, ehs[1:2], gligen=gl1)
+    assert torch.isfinite(out2).all()
+    # same kernels, other tile geometries / summation orders (M halves): bf16 rounding through ~200 layers, the size of the oracle distance
+    assert rel(out2[1:2], out1) < 4e-2, rel(out2[1:2], out1)
+    off = net.forward(x, 500, ehs[1:2], gligen=gl1, fuser_enabled=False)
+    assert rel(out1, off) > 1e-2
+    saved = dict(net.alpha)
+    try:
+        for k in net.alpha:
+            net.alpha[k] = 0.0
+        zero = net.forward(x, 500, ehs[1:2], gligen=gl1)
+    finally:
+        net.alpha.update(saved)
+    assert rel(zero, off) < 2e-3, rel(zero, off)

@@ -102,3 +102,62 @@ def test_pipeline_guided_sampling_vs_oracle_loop():
     err = rel(out, lat)
     print("pipeline 4-step latents rel-L2 vs oracle loop:", err)
     assert err < 8e-2
+
+
+def test_pipeline_lvd_plus_loop_vs_oracle_loop():
+    """lvd_plus = backward guidance + GLIGEN adapters (BASELINE configs[4] control flow, generation/lvd_plus.py:75-210): 4 DPM
+    steps on the gated TINY topology, guidance on the first 2, gligen_scheduled_sampling_beta = 0.5 so the fusers are switched off
+    from step 2 on (controllable_pipeline_text_to_video_synth.py:816-839); the guidance forward runs without the GLIGEN inputs
+    (models/pipelines.py:66-82).  Final latents vs the all-oracle loop."""
+    cfg = UNetConfig(attention_type="gated", **TINY)
+    sd = synthetic_state_dict(cfg, seed=1)
+    unet = UNet3DConditionModel.from_state_dict(sd, attention_type="gated", **TINY)
+    pipe = TextToVideoSDPipeline(unet=unet).to("cuda")
+    gen = torch.Generator().manual_seed(5)
+    Fr = 4
+    lat0 = torch.randn(1, 4, Fr, 16, 16, generator=gen)
+    pe, ne = torch.randn(1, 77, 64, generator=gen), torch.randn(1, 77, 64, generator=gen)
+    keys = [("down", 1, 0, 0), ("up", 1, 1, 0)]
+    boxes = [[[0.1 + 0.1 * f, 0.2, 0.6 + 0.1 * f, 0.8] for f in range(Fr)]]
+    pos = [[2]]
+    bg = dict(bboxes=boxes, object_positions=pos, loss_scale=5.0, loss_threshold=0.01, max_iter=1, max_index_step=2, fg_top_p=0.5,
+              bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03, guidance_attn_keys=keys, verbose=False)
+    gl_boxes = [[boxes[0][f]] for f in range(Fr)]
+    gl_phr = [["a bear"]] * Fr
+    phr_emb = torch.randn(Fr, 1, 64, generator=gen)
+    out = pipe(prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), height=128, width=128, num_frames=Fr, num_inference_steps=4,
+               guidance_scale=9.0, latents=lat0.clone(), output_type="latent", backward_guidance_kwargs=bg,
+               custom_latent_backward_guidance=hip_latent_backward_guidance, gligen_boxes=gl_boxes, gligen_phrases=gl_phr,
+               gligen_phrase_embeds=phr_emb, gligen_scheduled_sampling_beta=0.5).frames
+    # oracle loop
+    gb, ge, gm = torch.zeros(2 * Fr, 30, 4), torch.zeros(2 * Fr, 30, 64), torch.zeros(2 * Fr, 30)
+    for f in range(Fr):
+        for half in range(2):
+            gb[half * Fr + f, 0] = torch.tensor(boxes[0][f])
+            ge[half * Fr + f, 0] = phr_emb[f, 0]
+        gm[Fr + f, 0] = 1.0
+    gl = {"boxes": gb, "positive_embeddings": ge, "masks": gm}
+    sch = scheduler_ref.DPMSolverPP2M(timestep_spacing="leading", steps_offset=1)
+    sch.set_timesteps(4)
+    lat, loss = lat0.clone(), 10000.0
+    both = torch.cat([ne, pe])
+
+    def unet_fn(x, t, cond, save, save_keys):
+        unet_ref.unet_forward(sd, cfg, x, int(t), cond, save_attn_to_dict=save, save_keys=save_keys, stop_after_key=keys[-1])
+
+    hp = {k: v for k, v in bg.items() if k not in ("bboxes", "object_positions", "verbose")}
+    for i, t in enumerate(sch.timesteps):
+        lat, loss = guidance_ref.latent_backward_guidance(unet_fn, sch.alphas_cumprod, pe, i, boxes, pos, int(t), lat, loss, base_attn_dim=(16, 16), **hp)
+        with torch.no_grad():
+            eps = unet_ref.unet_forward(sd, cfg, lat.expand(2, -1, -1, -1, -1), int(t), both, gligen=gl, fuser_enabled=i < 2)
+        lat = sch.step(eps[0:1] + 9.0 * (eps[1:2] - eps[0:1]), lat)
+    with torch.no_grad():  # the same loop with the fusers never on must differ: the adapters were really exercised
+        lat_nf = lat0.clone()
+        sch2 = scheduler_ref.DPMSolverPP2M(timestep_spacing="leading", steps_offset=1)
+        sch2.set_timesteps(4)
+        e0 = unet_ref.unet_forward(sd, cfg, lat_nf.expand(2, -1, -1, -1, -1), int(sch2.timesteps[0]), both, gligen=gl, fuser_enabled=False)
+        e1 = unet_ref.unet_forward(sd, cfg, lat_nf.expand(2, -1, -1, -1, -1), int(sch2.timesteps[0]), both, gligen=gl, fuser_enabled=True)
+    assert rel(e0, e1) > 1e-3
+    err = rel(out, lat)
+    print("lvd_plus 4-step latents rel-L2 vs oracle loop:", err)
+    assert err < 8e-2
