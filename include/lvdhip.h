@@ -276,6 +276,13 @@ typedef struct {
   float grad_scale;                     /* loss_scale / (nobj * nkeys)  (utils/guidance.py:569-572, pipelines.py:101-112) */
   float* loss_partial;                  /* out [frames*heads*ntok]: per-(frame,head,token) loss terms, un-scaled */
   float* com_ws;                        /* workspace [frames, heads, ntok, 4] = (sum, com_y, com_x, -) */
+  /* optional terms of add_ca_loss_per_attn_map_to_loss (all off = the max-based top-k energy of the entry points' defaults) */
+  int32_t use_ratio_loss;               /* utils/guidance.py:312-323: (1 - sum(A*mask)/(sum(A)+eps))^2, mean over heads, instead of top-k */
+  float ratio_eps;                      /* 1e-2 in the reference */
+  float attn_sync_weight;               /* :401-430: w * mean over the NEXT frame's box of (A_f - A_f+1)^2, summed over heads */
+  float boxdiff_loss_scale;             /* :433-465: BoxDiff corner constraint on the row / column maxima */
+  int32_t boxdiff_normed;               /* 1: mean over (heads, W|H); 0: sum */
+  int32_t boxdiff_L;                    /* corner half-width (1 in the reference) */
 } lvd_ca_select_params;
 int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream);
 

@@ -187,8 +187,46 @@ __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_para
   __syncthreads();
 
   unsigned long long thr_fg = ~0ull, thr_bg = ~0ull;  // "nothing selected"
-  if (nmask > 0) thr_fg = radix_select(vals, flag, 1, p.P, kfg, hist, sh);
-  if (p.P - nmask > 0) thr_bg = radix_select(vals, flag, 0, p.P, kbg, hist, sh);
+  const bool ratio = p.use_ratio_loss != 0;
+  if (!ratio) {
+    if (nmask > 0) thr_fg = radix_select(vals, flag, 1, p.P, kfg, hist, sh);
+    if (p.P - nmask > 0) thr_bg = radix_select(vals, flag, 0, p.P, kbg, hist, sh);
+  }
+  // ratio-based energy (utils/guidance.py:312-323): act = sum(A*mask) / (sum(A) + eps); loss = mean over heads of (1 - act)^2
+  float r_in = 0.f, r_out = 0.f, ratio_loss = 0.f;  // dL/dA[p] = r_in inside the box, r_out outside
+  if (ratio) {
+    float sa = 0.f, sm = 0.f;
+    for (int i = threadIdx.x; i < p.P; i += blockDim.x) { sa += vals[i]; sm += flag[i] ? vals[i] : 0.f; }
+    sa = wave_sum(sa); sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[4 + (threadIdx.x >> 6)] = sm; }
+    __syncthreads();
+    sa = red[0] + red[1] + red[2] + red[3]; sm = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+    const float den = sa + p.ratio_eps, act = sm / den;
+    ratio_loss = (1.f - act) * (1.f - act) / (float)p.heads;
+    const float k2 = -2.f * (1.f - act) / ((float)p.heads * den * den);
+    r_in = k2 * (den - sm);
+    r_out = k2 * (-sm);
+  }
+  // attention sync (:401-430).  The reference crops BOTH frames with the box of the NEXT frame (its x_min..y_max were
+  // overwritten by the t1 loop), per head: w * mean_box((A_f - A_f+1)^2).  This block owns frame f: the pair (f, f+1) with
+  // box(f+1), and — as the second frame of the pair (f-1, f) — the gradient that pair sends to frame f, cropped with box(f).
+  // An empty next-frame box is a NaN in the reference (mean of an empty crop); here the pair contributes nothing.
+  const float sw = p.attn_sync_weight;
+  const float* Anext = nullptr;
+  const float* Aprev = nullptr;
+  int nx0 = 0, ny0 = 0, nx1 = 0, ny1 = 0;
+  float snext = 0.f, sprev = 0.f;
+  if (sw != 0.f) {
+    const long fstride = (long)p.heads * p.ntok * p.P;
+    if (f + 1 < p.frames) {
+      const int* b1 = p.boxes + ((long)obj * p.frames + f + 1) * 6;
+      nx0 = b1[0]; ny0 = b1[1]; nx1 = b1[2]; ny1 = b1[3];
+      const int n1 = max(0, nx1 - nx0) * max(0, ny1 - ny0);
+      if (n1 > 0) { Anext = A + fstride; snext = sw / (float)n1; }
+    }
+    if (f >= 1 && nmask > 0) { Aprev = A - fstride; sprev = sw / (float)nmask; }
+  }
 
   // centre-of-mass gradient coefficients: dL/dA[p] = gy*(y - cy)/S + gx*(x - cx)/S  (+ same with the t1 roles)
   float gy = 0.f, gx = 0.f, cy = 0.f, cx = 0.f, S = 1.f, com_loss = 0.f;
@@ -225,32 +263,74 @@ __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_para
     }
   }
 
-  float sfg = 0.f, sbg = 0.f;
+  float sfg = 0.f, sbg = 0.f, ssync = 0.f;
   const float gfg = -p.fg_weight / (float)kfg, gbg = p.bg_weight / (float)kbg;
   for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
     float a = vals[i];
     unsigned long long key = ((unsigned long long)__float_as_uint(a) << 12) | (unsigned)(4095 - i);
     float g = 0.f;
-    if (flag[i]) {
+    if (ratio) {
+      g += flag[i] ? r_in : r_out;
+    } else if (flag[i]) {
       if (key >= thr_fg) { sfg += a; g += gfg; }
     } else {
       if (key >= thr_bg) { sbg += a; g += gbg; }
     }
-    if (gy != 0.f || gx != 0.f) {
-      int y = i / p.W, x = i - y * p.W;
-      g += (gy * ((float)y - cy) + gx * ((float)x - cx)) / S;
+    const int y = i / p.W, x = i - y * p.W;
+    if (gy != 0.f || gx != 0.f) g += (gy * ((float)y - cy) + gx * ((float)x - cx)) / S;
+    if (Anext && y >= ny0 && y < ny1 && x >= nx0 && x < nx1) {
+      const float d = a - Anext[i];
+      ssync += d * d;
+      g += 2.f * snext * d;
     }
+    if (Aprev && flag[i]) g -= 2.f * sprev * (Aprev[i] - a);
     dA[i] = c * g;
   }
-  sfg = wave_sum(sfg); sbg = wave_sum(sbg);
+  sfg = wave_sum(sfg); sbg = wave_sum(sbg); ssync = wave_sum(ssync);
   int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[w] = sfg; red[4 + w] = sbg; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float tf = red[0] + red[1] + red[2] + red[3], tb = red[4] + red[5] + red[6] + red[7];
-    float loss = p.fg_weight * (1.f - tf / (float)kfg) + p.bg_weight * (tb / (float)kbg) + com_loss;
-    p.loss_partial[b] = wt * loss;
+  const float tf = red[0] + red[1] + red[2] + red[3], tb = red[4] + red[5] + red[6] + red[7];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = ssync;
+  __syncthreads();
+  const float tsync = red[0] + red[1] + red[2] + red[3];
+  float loss = ratio ? ratio_loss : p.fg_weight * (1.f - tf / (float)kfg) + p.bg_weight * (tb / (float)kbg);
+  loss += com_loss + snext * tsync;
+
+  // BoxDiff corner constraint (:240-287, 433-465): |max over rows/columns of A - max of the mask| on the corner columns/rows;
+  // the gradient goes to the (first) arg-max of each column / row.  dA was written above: the adds below are ordered by barriers.
+  if (p.boxdiff_loss_scale > 0.f) {
+    const int L = p.boxdiff_L, Hh = p.H, Ww = p.W;
+    float cc = 0.f;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: columns (max over y), pass 1: rows (max over x)
+      const int n = pass == 0 ? Ww : Hh, m = pass == 0 ? Hh : Ww;
+      const int lo = pass == 0 ? x0 : y0, hi2 = pass == 0 ? x1 : y1;
+      const float norm = p.boxdiff_normed ? 1.f / ((float)p.heads * (float)n) : 1.f;
+      for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const bool corner = (j >= max(lo - L, 0) && j < min(lo + L + 1, n)) || (j >= max(hi2 - L, 0) && j < min(hi2 + L + 1, n));
+        if (!corner) continue;
+        float best = -1.f;
+        int arg = 0;
+        for (int q = 0; q < m; ++q) {
+          const int idx = pass == 0 ? q * Ww + j : j * Ww + q;
+          if (vals[idx] > best) { best = vals[idx]; arg = idx; }
+        }
+        const float target = (nmask > 0 && j >= lo && j < hi2) ? 1.f : 0.f;
+        const float diff = best - target;
+        cc += fabsf(diff) * norm;
+        const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        dA[arg] += c * p.boxdiff_loss_scale * norm * sg;
+      }
+      __syncthreads();
+    }
+    cc = wave_sum(cc);
+    if ((threadIdx.x & 63) == 0) red[w] = cc;
+    __syncthreads();
+    loss += p.boxdiff_loss_scale * (red[0] + red[1] + red[2] + red[3]);
   }
+  if (threadIdx.x == 0) p.loss_partial[b] = wt * loss;
 }
 
 // ------------------------------------------------------------------------------------ 3. dQ

@@ -26,8 +26,12 @@ from .engine import HipUNet3D, Tape, Geom
 
 DEFAULT_GUIDANCE_ATTN_KEYS = [("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0)]  # models/pipelines.py:13-18
 
-_UNSUPPORTED = dict(use_ratio_based_loss=False, use_ce_based_loss=False, exclude_bg_heads=False, smooth_attn=False,
-                    attn_renorm=False, attn_sync_weight=0.0, boxdiff_loss_scale=0.0, upsample_scale=1)
+# loss options of utils/guidance.py:160-526 that are NOT built (none is reachable from generate.py's command line): they raise
+_UNSUPPORTED = dict(use_ce_based_loss=False, exclude_bg_heads=False, smooth_attn=False, attn_renorm=False, upsample_scale=1,
+                    use_max_based_loss=True)
+# optional terms that ARE built into the fused loss kernel (generate.py:78-106, generation/lvd.py:85-106 forward them)
+_LOSS_OPTIONS = ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "com_loss_scale", "use_ratio_based_loss", "attn_sync_weight",
+                 "boxdiff_loss_scale", "boxdiff_normed", "boxdiff_L")
 
 
 def scale_proportion(box, H, W):
@@ -80,7 +84,8 @@ MAX_TOKENS_PER_LAUNCH = 16  # csrc/guidance_loss.hip MAXTOK: object-token column
 
 
 def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext, grad_scale, fg_weight, bg_weight,
-                          com_loss_scale, loss_partial, want_dq=True):
+                          com_loss_scale, loss_partial, want_dq=True, use_ratio_based_loss=False, attn_sync_weight=0.0,
+                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1):
     """One guidance key: q [frames*P, heads*64] bf16, k [ntext, heads*64] bf16 (strided ok).
 
     Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ.  Layouts with
@@ -93,7 +98,9 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
             sub = layout.token_slice(c0, min(layout.ntok, c0 + MAX_TOKENS_PER_LAUNCH))
             n = frames * heads * sub.ntok
             dq = ca_energy_loss_and_dq(q, k, heads, frames, sub, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
-                                       com_loss_scale=com_loss_scale, loss_partial=loss_partial[off:off + n], want_dq=want_dq)
+                                       com_loss_scale=com_loss_scale, loss_partial=loss_partial[off:off + n], want_dq=want_dq,
+                                       use_ratio_based_loss=use_ratio_based_loss, attn_sync_weight=attn_sync_weight,
+                                       boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed, boxdiff_L=boxdiff_L)
             off += n
             if want_dq:
                 dq_total = dq if dq_total is None else ops.add(dq_total, dq, out=dq_total)
@@ -118,6 +125,10 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
     b.tok_obj, b.boxes, b.tok_weight, b.nobj = layout.tok_obj.data_ptr(), layout.boxes.data_ptr(), layout.tok_weight.data_ptr(), layout.nobj
     b.fg_weight, b.bg_weight, b.com_loss_scale, b.grad_scale = fg_weight, bg_weight, com_loss_scale, grad_scale
     b.loss_partial, b.com_ws = loss_partial.data_ptr(), com_ws.data_ptr()
+    b.use_ratio_loss, b.ratio_eps, b.attn_sync_weight = int(bool(use_ratio_based_loss)), 1.0e-2, float(attn_sync_weight)
+    b.boxdiff_loss_scale, b.boxdiff_normed, b.boxdiff_L = float(boxdiff_loss_scale), int(bool(boxdiff_normed)), int(boxdiff_L)
+    if use_ratio_based_loss:
+        warnings.warn("Using ratio-based loss, which is deprecated. Max-based loss is recommended. The scale may be different.")
     hip.check(hip.lib().lvdhip_ca_select(C.byref(b), st), "ca_select")
     if not want_dq:
         return None
@@ -133,7 +144,8 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
 
 
 def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_positions, guidance_attn_keys, *, loss_scale,
-                           fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0, com_loss_scale=0.0, latent_scale=1.0):
+                           fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0, com_loss_scale=0.0, latent_scale=1.0, saved_attn=None,
+                           **loss_options):
     """One recorded forward + fused loss + hand-scheduled backward.
 
     Returns (loss [1] fp32 device tensor, already multiplied by loss_scale; grad (1,4,F,h,w) fp32)."""
@@ -161,9 +173,15 @@ def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_p
         if lay is None:
             lay = layouts[(g.H, g.W)] = GuidanceLayout(bboxes, object_positions, frames, g.H, g.W, fg_top_p, bg_top_p, latents.device)
         dq = ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=text.ntext, grad_scale=grad_scale, fg_weight=fg_weight,
-                                   bg_weight=bg_weight, com_loss_scale=com_loss_scale, loss_partial=partial[off:off + n])
+                                   bg_weight=bg_weight, com_loss_scale=com_loss_scale, loss_partial=partial[off:off + n], **loss_options)
         tape.accumulate(q, dq)
         off += n
+    if saved_attn is not None:  # visualisation only (return_saved_attn): the full maps, as AttnProcessor.__call__ would have saved them
+        for key in keys:
+            q, k, heads, g = collect["q"][key]
+            qf = q.float().reshape(g.B * g.F, g.HW, heads, 64).permute(0, 2, 1, 3)
+            kf = k.float().reshape(text.B, text.ntext, heads, 64).permute(0, 2, 3, 1).repeat_interleave(g.F, 0)
+            saved_attn[key] = (qf @ kf * 0.125).softmax(-1).cpu()
     loss = ops.reduce_sum(partial, grad_scale)
     tape.backward()
     g0 = Geom(1, frames, latents.shape[3], latents.shape[4])
@@ -204,11 +222,12 @@ def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes
     for k, default in _UNSUPPORTED.items():
         if k in kwargs and kwargs[k] != default:
             raise NotImplementedError(f"guidance option {k}={kwargs[k]!r} is outside the hot path built here")
-    if return_saved_attn:
-        raise NotImplementedError("attention maps are never materialised on the HIP path (return_saved_attn)")
+    if return_saved_attn not in (False, None, "first", "last"):
+        raise ValueError(return_saved_attn)
+    saved_attn_to_return = None
     if guidance_attn_keys is None:
         guidance_attn_keys = DEFAULT_GUIDANCE_ATTN_KEYS
-    loss_kw = {k: kwargs[k] for k in ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "com_loss_scale") if k in kwargs}
+    loss_kw = {k: kwargs[k] for k in _LOSS_OPTIONS if k in kwargs}
     text = cond_embeddings if hasattr(cond_embeddings, "kv") else engine.encode_text(cond_embeddings)
     iteration = 0
     loss_val = float(loss)
@@ -219,11 +238,18 @@ def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes
             print(f"time index {index}, loss: {loss_val / loss_scale:.3f} (de-scaled with scale {loss_scale:.1f}), loss threshold: {loss_threshold:.3f}")
         if len(bboxes) == 0:
             # the reference crashes in autograd here and generate.py skips the prompt; no boxes = no guidance
-            return latents, torch.zeros((), device=latents.device)
+            z = torch.zeros((), device=latents.device)
+            return (latents, z, None) if return_saved_attn else (latents, z)
         while loss_val / loss_scale > loss_threshold and iteration < max_iter and index < max_index_step:
             lat_in = scheduler.scale_model_input(latents, t) if hasattr(scheduler, "scale_model_input") else latents
+            # models/pipelines.py:85-97: "first" keeps the maps of iteration 0, "last" those of iteration max_iter - 1 (not saved if
+            # the loop returns earlier); the maps are materialised with torch only then — the loss kernels never need them
+            want_maps = (return_saved_attn == "first" and iteration == 0) or (return_saved_attn == "last" and iteration == max_iter - 1)
+            maps = {} if want_maps else None
             loss_t, grad = guidance_loss_and_grad(engine, lat_in, t, text, bboxes, object_positions, guidance_attn_keys,
-                                                  loss_scale=loss_scale, **loss_kw)
+                                                  loss_scale=loss_scale, saved_attn=maps, **loss_kw)
+            if want_maps:
+                saved_attn_to_return = maps
             if hasattr(scheduler, "alphas_cumprod"):
                 scale = float((1 - scheduler.alphas_cumprod[int(t)]) ** 0.5)  # classifier-guidance scaling, pipelines.py:124-132
             else:
@@ -237,4 +263,6 @@ def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes
             iteration += 1
             if verbose:
                 print(f"time index {index}, loss: {loss_val / loss_scale:.3f}, loss threshold: {loss_threshold:.3f}, iteration: {iteration}")
+    if return_saved_attn:
+        return latents, loss, saved_attn_to_return
     return latents, loss

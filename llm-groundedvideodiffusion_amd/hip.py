@@ -120,6 +120,8 @@ class CaSelectParams(C.Structure):
         ("tok_obj", C.c_void_p), ("boxes", C.c_void_p), ("tok_weight", C.c_void_p), ("nobj", i32),
         ("fg_weight", f32), ("bg_weight", f32), ("com_loss_scale", f32),
         ("grad_scale", f32), ("loss_partial", C.c_void_p), ("com_ws", C.c_void_p),
+        ("use_ratio_loss", i32), ("ratio_eps", f32), ("attn_sync_weight", f32), ("boxdiff_loss_scale", f32),
+        ("boxdiff_normed", i32), ("boxdiff_L", i32),
     ]
 
 

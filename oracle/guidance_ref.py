@@ -34,8 +34,12 @@ def _com(x, h_range, w_range):
 
 
 def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
-                    bg_weight=1.0, com_loss_scale=0.0):
-    """attn_map: (frames, heads, P, tokens) probabilities.  Returns the un-normalised loss contribution."""
+                    bg_weight=1.0, com_loss_scale=0.0, use_ratio_based_loss=False, eps=1.0e-2, attn_sync_weight=0.0,
+                    boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1):
+    """attn_map: (frames, heads, P, tokens) probabilities.  Returns the un-normalised loss contribution.
+    utils/guidance.py:160-526 (add_ca_loss_per_attn_map_to_loss) with upsample_scale = 1, no smoothing / renorm / CE:
+    max-based top-k energy (default) or the deprecated ratio-based energy (:312-323), attention sync between consecutive frames
+    (:401-430), BoxDiff corner constraint (:240-287, 433-465), centre-of-mass position / velocity terms (:467-522)."""
     n_f, heads, P, _ = attn_map.shape
     H, W = get_hw_from_attn_dim(P, base_attn_dim)
     dev = attn_map.device
@@ -50,7 +54,16 @@ def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=
             mask = torch.zeros(H, W, device=dev)
             x0, y0, x1, y1 = scale_proportion(box, H, W)
             mask[y0:y1, x0:x1] = 1
+            if boxdiff_loss_scale > 0:
+                corner_x, corner_y = torch.zeros(1, W, device=dev), torch.zeros(1, H, device=dev)
+                L = boxdiff_L
+                corner_x[:, max(x0 - L, 0):min(x0 + L + 1, W)] = 1.0
+                corner_x[:, max(x1 - L, 0):min(x1 + L + 1, W)] = 1.0
+                corner_y[:, max(y0 - L, 0):min(y0 + L + 1, H)] = 1.0
+                corner_y[:, max(y1 - L, 0):min(y1 + L + 1, H)] = 1.0
             mask_t1 = torch.zeros(H, W, device=dev)
+            # NB: the reference re-uses the names x_min..y_max for the NEXT frame's box here, so the attention-sync crop below is
+            # taken with the box of frame f1 (utils/guidance.py:273-276 overwrite :250-252 before :418-423 read them)
             x0, y0, x1, y1 = scale_proportion(obj_boxes[f1], H, W)
             mask_t1[y0:y1, x0:x1] = 1
             k_fg = int((mask.sum() * fg_top_p).long().clamp_(min=1))
@@ -59,8 +72,25 @@ def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=
             for pos in object_positions[obj_idx]:
                 a = attn_map[f, :, :, pos].float()      # (heads, P)
                 a1 = attn_map[f1, :, :, pos].float()
-                obj_loss = obj_loss + fg_weight * (1 - (a * m1).topk(k_fg).values.mean(1)).sum(0)
-                obj_loss = obj_loss + bg_weight * (a * (1 - m1)).topk(k_bg).values.mean(1).sum(0)
+                if use_ratio_based_loss:
+                    act = (a.view(heads, H, W) * mask).reshape(heads, -1).sum(-1) / (a.sum(-1) + eps)
+                    obj_loss = obj_loss + torch.mean((1 - act) ** 2)
+                else:
+                    obj_loss = obj_loss + fg_weight * (1 - (a * m1).topk(k_fg).values.mean(1)).sum(0)
+                    obj_loss = obj_loss + bg_weight * (a * (1 - m1)).topk(k_bg).values.mean(1).sum(0)
+                if attn_sync_weight != 0.0 and f != n_f - 1:
+                    a2 = attn_map[f + 1, :, :, pos].float()
+                    d = a.view(heads, H, W)[:, y0:y1, x0:x1] - a2.view(heads, H, W)[:, y0:y1, x0:x1]
+                    obj_loss = obj_loss + (d ** 2).mean(dim=(1, 2)).sum(0) * attn_sync_weight
+                if boxdiff_loss_scale > 0:
+                    a2d = a.view(heads, H, W)
+                    mx, my = a2d.max(dim=1).values, a2d.max(dim=2).values          # (heads, W), (heads, H)
+                    mmx, mmy = mask[None].max(dim=1).values, mask[None].max(dim=2).values
+                    if boxdiff_normed:
+                        cc = ((mx - mmx).abs() * corner_x).mean() + ((my - mmy).abs() * corner_y).mean()
+                    else:
+                        cc = ((mx - mmx).abs() * corner_x).sum() + ((my - mmy).abs() * corner_y).sum()
+                    obj_loss = obj_loss + cc * boxdiff_loss_scale
                 if com_loss_scale > 0 and mask.sum() > 0:
                     ch, cw = _com(a.view(heads, H, W), h_range, w_range)
                     mh, mw = _com(mask[None], h_range, w_range)

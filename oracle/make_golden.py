@@ -285,6 +285,28 @@ def main():
         store[f"grad0_{name}"] = grads[0].numpy()
         store[f"grad1_{name}"] = grads[1].numpy()
         print("loss", name, loss.item())
+    # optional terms the reference's command line can switch on (generate.py:78-106, generation/lvd.py:85-106): deprecated ratio
+    # energy, attention sync, BoxDiff corner constraint.  Boxes without an empty frame: with an empty NEXT-frame box the reference's
+    # attention-sync crop is empty and its mean is NaN.
+    bboxes2 = [[[0.1, 0.2, 0.55, 0.8], [0.15, 0.2, 0.6, 0.8], [0.2, 0.2, 0.65, 0.8], [0.25, 0.2, 0.7, 0.8]],
+               [[0.5, 0.5, 0.9, 0.95], [0.45, 0.5, 0.85, 0.95], [0.4, 0.45, 0.8, 0.9], [0.0, 0.3, 0.3, 1.0]]]
+    store["bboxes2"] = np.array(bboxes2)
+    import warnings
+    cases2 = {"ratio": dict(use_ratio_based_loss=True, com_loss_scale=0.02),
+              "sync": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, attn_sync_weight=3.0),
+              "boxdiff": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, boxdiff_loss_scale=0.7, boxdiff_normed=True),
+              "boxdiff_sum": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, boxdiff_loss_scale=0.05, boxdiff_normed=False, boxdiff_L=2),
+              "all": dict(fg_top_p=0.3, bg_top_p=0.6, fg_weight=1.5, bg_weight=2.5, attn_sync_weight=1.0, boxdiff_loss_scale=0.4, com_loss_scale=0.03)}
+    for name, kw in cases2.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss = guidance.compute_ca_lossv3(saved_attn=maps, bboxes=bboxes2, object_positions=object_positions,
+                                              guidance_attn_keys=list(maps.keys()), base_attn_dim=(H, W), **kw)
+        grads = torch.autograd.grad(loss, list(maps.values()))
+        store[f"loss_{name}"] = np.array(loss.item())
+        store[f"grad0_{name}"] = grads[0].numpy()
+        store[f"grad1_{name}"] = grads[1].numpy()
+        print("loss", name, loss.item())
     np.savez_compressed(os.path.join(OUT, "guidance_loss.npz"), **store)
 
     # ------------------------------------------------------------------ (d) latent_backward_guidance on the tiny UNet

@@ -105,6 +105,33 @@ def test_fused_loss_kernels_vs_oracle(com):
     assert rel(dq, gq) < 1.5e-2, rel(dq, gq)   # dq is stored in bf16
 
 
+@pytest.mark.parametrize("case", ["ratio", "sync", "boxdiff", "boxdiff_sum", "all"])
+def test_fused_loss_optional_terms_vs_oracle_and_reference(case):
+    """Ratio-based energy, attention sync, BoxDiff corner constraint in the fused kernel: (i) on projected Q/K vs autograd through
+    the oracle, (ii) on the reference's own maps: the kernel's loss / dA against the golden loss / gradient of utils/guidance.py."""
+    from test_oracle import LOSS_VARIANTS
+    kw = dict(fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0, com_loss_scale=0.0)
+    kw.update(LOSS_VARIANTS[case])
+    frames, heads, Hh, Ww, nt = 4, 3, 8, 12, 77
+    P, C = Hh * Ww, heads * 64
+    q = rnd(frames * P, C, seed=1, scale=1.5).bfloat16()
+    k = rnd(nt, C, seed=2).bfloat16()
+    g = np.load(os.path.join(G, "guidance_loss.npz"))
+    bboxes, pos = g["bboxes2"].tolist(), [[2, 3], [6]]
+    qa = q.float().requires_grad_(True)
+    probs = (qa.reshape(frames, P, heads, 64).permute(0, 2, 1, 3) @ k.float().reshape(nt, heads, 64).permute(1, 2, 0)[None] * 0.125).softmax(-1)
+    ref = guidance_ref.compute_ca_loss({"k": probs}, bboxes, pos, ["k"], (Hh, Ww), **kw) * 5.0
+    (gq,) = torch.autograd.grad(ref, qa)
+    lay = guidance.GuidanceLayout(bboxes, pos, frames, Hh, Ww, kw["fg_top_p"], kw["bg_top_p"], DEV)
+    partial = torch.zeros(frames * heads * 3, device=DEV)
+    gs = 5.0 / len(bboxes)
+    hip_kw = {kk: v for kk, v in kw.items() if kk not in ("fg_top_p", "bg_top_p")}
+    dq = guidance.ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=nt, grad_scale=gs, loss_partial=partial, **hip_kw)
+    loss = ops.reduce_sum(partial, gs).item()
+    assert abs(loss - ref.item()) < 3e-4 * abs(ref.item()), (case, loss, ref.item())
+    assert rel(dq, gq) < 1.5e-2, (case, rel(dq, gq))
+
+
 def test_fused_loss_many_object_tokens_and_bounds():
     """More object tokens than one launch keeps per query (csrc/guidance_loss.hip MAXTOK = 16) run in token chunks — loss and dQ
     are per-token / linear in the tokens; a token position beyond the text length raises IndexError like the reference's indexing."""
@@ -132,6 +159,36 @@ def test_fused_loss_many_object_tokens_and_bounds():
     with pytest.raises(IndexError):
         guidance.ca_energy_loss_and_dq(q, k, heads, frames, bad, ntext=nt, grad_scale=gs, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.0,
                                        loss_partial=torch.zeros(frames * heads * 2, device=DEV))
+
+
+def test_return_saved_attn_first_and_last():
+    """return_saved_attn of models/pipelines.py:85-97: the maps of the first / last iteration come back as the third element, equal to the
+    softmax of the projected queries and text keys (the reference's AttnProcessor save path)."""
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=0)
+    net = HipUNet3D(cfg, sd)
+    keys = [("down", 1, 0, 0), ("up", 1, 1, 0)]
+    sched = scheduler_ref.DPMSolverPP2M()
+    lat0 = rnd(1, 4, 4, 16, 16, seed=3)
+    cond = rnd(1, 77, cfg.cross_attention_dim, seed=4)
+    boxes = [[[0.1, 0.2, 0.6, 0.8]] * 4]
+    hp = dict(loss_scale=5.0, loss_threshold=0.01, max_index_step=10, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, guidance_attn_keys=keys)
+    for mode in ("first", "last"):
+        lat, loss, maps = guidance.hip_latent_backward_guidance(sched, net, cond, 0, boxes, [[2]], 801, lat0.clone(), torch.tensor(10000.0), max_iter=2,
+                                                                return_saved_attn=mode, **hp)
+        assert set(maps) == set(keys)
+        saved = {}
+        from oracle import unet_ref
+        x_in = lat0.cpu() if mode == "first" else None
+        for key in keys:
+            m = maps[key]
+            assert m.shape[0] == 4 and m.shape[-1] == 77 and torch.allclose(m.sum(-1), torch.ones_like(m.sum(-1)), atol=1e-4)
+        if mode == "first":
+            unet_ref.unet_forward({k: v.cpu() for k, v in sd.items()}, cfg, x_in, 801, cond.cpu(), save_attn_to_dict=saved, save_keys=keys, stop_after_key=keys[-1])
+            for key in keys:
+                assert rel(maps[key], saved[key]) < 5e-2, (key, rel(maps[key], saved[key]))
+    with pytest.raises(ValueError):
+        guidance.hip_latent_backward_guidance(sched, net, cond, 0, boxes, [[2]], 801, lat0.clone(), torch.tensor(10000.0), max_iter=1, return_saved_attn="all", **hp)
 
 
 def test_guidance_step_vs_reference_golden():

@@ -134,7 +134,7 @@ def test_guidance_layout_matches_oracle_box_logic():
         assert list(arr[f]) == [x0, y0, x1, y1, kfg, kbg]
     assert lay.tok_ids.tolist() == [2, 5] and lay.tok_weight.tolist() == [0.5, 0.5]
     with pytest.raises(NotImplementedError):
-        guidance.hip_latent_backward_guidance(None, None, None, 0, boxes, [[2]], 1, None, 1.0, use_ratio_based_loss=True)
+        guidance.hip_latent_backward_guidance(None, None, None, 0, boxes, [[2]], 1, None, 1.0, use_ce_based_loss=True)  # CE / smoothing / renorm variants are not built
     with pytest.raises(KeyError):
         guidance._last_key_in_order(type("E", (), {"cfg": UNetConfig(**TINY)})(), [("down", 3, 0, 0)])
 

@@ -73,6 +73,27 @@ def test_guidance_loss_matches_reference(case, kw):
     assert rel(g0, g[f"grad0_{case}"][0]) < 1e-4 and rel(g1, g[f"grad1_{case}"][0]) < 1e-4
 
 
+LOSS_VARIANTS = {  # the cases of oracle/make_golden.py section (c), second box set
+    "ratio": dict(use_ratio_based_loss=True, com_loss_scale=0.02),
+    "sync": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, attn_sync_weight=3.0),
+    "boxdiff": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, boxdiff_loss_scale=0.7, boxdiff_normed=True),
+    "boxdiff_sum": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, boxdiff_loss_scale=0.05, boxdiff_normed=False, boxdiff_L=2),
+    "all": dict(fg_top_p=0.3, bg_top_p=0.6, fg_weight=1.5, bg_weight=2.5, attn_sync_weight=1.0, boxdiff_loss_scale=0.4, com_loss_scale=0.03),
+}
+
+
+@pytest.mark.parametrize("case", sorted(LOSS_VARIANTS))
+def test_optional_loss_terms_match_reference(case):
+    """Ratio-based energy, attention sync, BoxDiff corner constraint (utils/guidance.py:312-323, 401-465): the oracle's restatement
+    against the reference's own loss value and autograd gradients."""
+    g = np.load(os.path.join(G, "guidance_loss.npz"))
+    maps = {("down", 1, 0, 0): torch.from_numpy(g["maps_0"])[0].requires_grad_(True), ("up", 1, 1, 0): torch.from_numpy(g["maps_1"])[0].requires_grad_(True)}
+    loss = guidance_ref.compute_ca_loss(maps, g["bboxes2"].tolist(), [[2, 3], [6]], list(maps.keys()), (8, 12), **LOSS_VARIANTS[case])
+    assert abs(loss.item() - float(g[f"loss_{case}"])) < 1e-4 * abs(float(g[f"loss_{case}"]))
+    g0, g1 = torch.autograd.grad(loss, list(maps.values()))
+    assert rel(g0, g[f"grad0_{case}"][0]) < 1e-4 and rel(g1, g[f"grad1_{case}"][0]) < 1e-4
+
+
 def test_guidance_step_matches_reference():
     g = np.load(os.path.join(G, "guidance_step.npz"))
     cfg = UNetConfig(**TINY)
