@@ -51,7 +51,8 @@ def build_parser():
     p.add_argument("--cache-dir", default="cache", help="directory holding cache_{prompt_type}_{template}_{model}.json")
     p.add_argument("--prompts-file", default=None, help="one prompt per line (prompt types other than demo)")
     p.add_argument("--synthetic-weights", action="store_true", help="random-init weights of the real topology (no checkpoint on disk)")
-    p.add_argument("--checkpoint", default=None, help="torch-saved reference state_dict of the UNet")
+    p.add_argument("--checkpoint", default=None, help="torch-saved reference state_dict of the UNet, or a local Hugging Face snapshot directory "
+                   "(e.g. .../models--cerspense--zeroscope_v2_576w/snapshots/<rev>) holding unet/config.json + diffusion_pytorch_model.safetensors")
     p.add_argument("--img-root", default="img_generations")
     return p
 
@@ -78,6 +79,8 @@ def main(argv=None):
             ops.load_gemm_autotune_table(args.gemm_autotune_table)  # same tile geometry per shape in every rank / run
         if args.synthetic_weights:
             _common.configure(state_dict="synthetic")
+        elif args.checkpoint and os.path.isdir(args.checkpoint):
+            _common.configure(state_dict=args.checkpoint)  # local HF snapshot directory: <dir>/unet/{config.json, diffusion_pytorch_model.safetensors}
         elif args.checkpoint:
             _common.configure(state_dict=torch.load(args.checkpoint, map_location="cpu"))
         _common.configure(device=f"cuda:{local_rank}")

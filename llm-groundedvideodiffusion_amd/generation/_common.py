@@ -55,7 +55,12 @@ class Method:
         if isinstance(sd, str) and sd == "synthetic":
             ucfg = UNetConfig(**{k: v for k, v in cfg_kw.items() if k in UNetConfig.__dataclass_fields__})
             sd = synthetic_state_dict(ucfg, seed=0, device=_components["device"])
-        unet = UNet3DConditionModel.from_state_dict(sd, device=_components["device"], **cfg_kw)
+        if isinstance(sd, str):  # a local Hugging Face snapshot directory, as generation/lvd.py:39-44 loads it (subfolder "unet")
+            import os
+            unet = UNet3DConditionModel.from_pretrained(sd, subfolder="unet" if os.path.isdir(os.path.join(sd, "unet")) else None,
+                                                        device=_components["device"], **cfg_kw)
+        else:
+            unet = UNet3DConditionModel.from_state_dict(sd, device=_components["device"], **cfg_kw)
         vae = _components["vae"]
         if isinstance(vae, (dict, str)):
             from ..vae import HipVAEDecoder

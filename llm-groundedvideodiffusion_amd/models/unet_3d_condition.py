@@ -4,7 +4,7 @@
 Differences that are deliberate and loud:
   * no autograd: the guidance gradient comes from `lvd_amd.guidance.hip_latent_backward_guidance` (plug it into the
     pipeline's `custom_latent_backward_guidance`); calling the reference's autograd-based loop on this model raises.
-  * `from_pretrained` needs network/hub files — use `from_state_dict` (reference checkpoints load by key name).
+  * `from_pretrained` reads a LOCAL Hugging Face snapshot directory (config.json + safetensors / bin); hub ids are not downloaded.
 """
 import types
 from collections import OrderedDict
@@ -73,10 +73,40 @@ class UNet3DConditionModel(nn.Module):
         m.load_state_dict(state_dict)
         return m.to(device)
 
+    _CONFIG_KEYS = ("sample_size", "in_channels", "out_channels", "down_block_types", "up_block_types", "block_out_channels", "layers_per_block",
+                    "downsample_padding", "mid_block_scale_factor", "act_fn", "norm_num_groups", "norm_eps", "cross_attention_dim",
+                    "attention_head_dim", "num_attention_heads", "attention_type")
+
     @classmethod
-    def from_pretrained(cls, *a, **k):
-        raise RuntimeError("from_pretrained needs the HF hub (no network here): load the checkpoint's state_dict and use "
-                           "UNet3DConditionModel.from_state_dict(state_dict, **config)")
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", **overrides):
+        """Local Hugging Face snapshot directory (generation/lvd.py:39-44 `UNet3DConditionModel.from_pretrained(key, subfolder="unet")`):
+        `<dir>[/<subfolder>]/config.json` + `diffusion_pytorch_model.safetensors` (or `.fp16.safetensors`, or `.bin`).  Hub ids are not
+        resolved (no network): pass the directory of an already downloaded snapshot, e.g. .../cerspense--zeroscope_v2_576w/snapshots/<rev>."""
+        import json
+        import os
+        root = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
+        cfg_path = os.path.join(root, "config.json")
+        if not os.path.isfile(cfg_path):
+            raise RuntimeError(f"{cfg_path} not found: from_pretrained needs a LOCAL snapshot directory (hub ids cannot be downloaded here); "
+                               "or load a state_dict and use UNet3DConditionModel.from_state_dict(state_dict, **config)")
+        with open(cfg_path) as f:
+            raw = json.load(f)
+        config = {k: (tuple(v) if isinstance(v, list) else v) for k, v in raw.items() if k in cls._CONFIG_KEYS}
+        config.update(overrides)
+        sd = None
+        for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"):
+            if os.path.isfile(os.path.join(root, name)):
+                from safetensors.torch import load_file
+                sd = load_file(os.path.join(root, name))
+                break
+        if sd is None:
+            for name in ("diffusion_pytorch_model.bin", "diffusion_pytorch_model.fp16.bin"):
+                if os.path.isfile(os.path.join(root, name)):
+                    sd = torch.load(os.path.join(root, name), map_location="cpu", weights_only=True)
+                    break
+        if sd is None:
+            raise RuntimeError(f"no diffusion_pytorch_model.safetensors / .bin under {root}")
+        return cls.from_state_dict(sd, device=device, **config)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         missing = [k for k in self._shapes if k not in state_dict]

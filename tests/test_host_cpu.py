@@ -139,6 +139,30 @@ def test_guidance_layout_matches_oracle_box_logic():
         guidance._last_key_in_order(type("E", (), {"cfg": UNetConfig(**TINY)})(), [("down", 3, 0, 0)])
 
 
+def test_from_pretrained_reads_a_local_snapshot(tmp_path):
+    """generation/lvd.py:39-44 loads `UNet3DConditionModel.from_pretrained(key, subfolder="unet")`: a local snapshot directory
+    (config.json + diffusion_pytorch_model.safetensors) loads by key name; a hub id without files raises loudly."""
+    import json
+    from safetensors.torch import save_file
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=0)
+    d = tmp_path / "snap" / "unet"
+    d.mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    conf = dict(_class_name="UNet3DConditionModel", _diffusers_version="0.27.2", sample_size=32, in_channels=4, out_channels=4,
+                block_out_channels=list(TINY["block_out_channels"]), layers_per_block=TINY["layers_per_block"],
+                cross_attention_dim=TINY["cross_attention_dim"], attention_head_dim=64, norm_num_groups=32, norm_eps=1e-5, act_fn="silu",
+                down_block_types=["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"], up_block_types=["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3,
+                downsample_padding=1, mid_block_scale_factor=1)
+    (d / "config.json").write_text(json.dumps(conf))
+    m = UNet3DConditionModel.from_pretrained(str(tmp_path / "snap"), subfolder="unet")
+    assert m.config.block_out_channels == tuple(TINY["block_out_channels"]) and m.config.sample_size == 32
+    got = m.state_dict()
+    assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(RuntimeError):
+        UNet3DConditionModel.from_pretrained("cerspense/zeroscope_v2_576w", subfolder="unet")
+
+
 def test_two_rank_sharding_is_seed_invariant():
     """world_size-2 gloo: ranks take prompt indices i % 2 == rank; seeds are a function of the global index
     (generate.py:325-335), so the union over ranks equals the single-process assignment."""
