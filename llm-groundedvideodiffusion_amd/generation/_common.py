@@ -1,7 +1,8 @@
 """Shared runner of the generation methods (the five reference modules differ only in defaults and in which conditioning
-they switch on).  Components that are 'next' rows of the scope table (CLIP text encoder + tokenizer, VAE decoder) and the
-checkpoint itself are INJECTED with `configure(...)`: nothing can be downloaded here, and the reference's
-`from_pretrained(hub_id)` calls have no offline equivalent."""
+they switch on).  The checkpoint and the components around the denoiser are handed over with `configure(...)` — nothing can be
+downloaded here: `state_dict` = reference-named UNet weights, a LOCAL Hugging Face snapshot directory (the offline form of the
+reference's `from_pretrained(key, subfolder="unet")`) or "synthetic"; `vae` / `text_encoder` = state_dicts run by the HIP VAE decoder /
+CLIP text encoder (or callables); `tokenizer` = a callable (the CLIP vocabulary files are not in this image)."""
 import os
 
 import numpy as np

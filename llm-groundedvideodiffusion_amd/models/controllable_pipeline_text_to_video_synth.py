@@ -3,9 +3,10 @@
 
 In scope: timestep setup, latent preparation, GLIGEN tensor assembly (:736-814), fuser scheduled sampling
 (:816-817,838-839), the denoising loop with backward guidance, CFG and the DPM-Solver++ update (:833-958).
-Next rows (§8f, not built): CLIP text encoding and VAE decoding — pass `prompt_embeds`/`negative_prompt_embeds`
-(and, for GLIGEN, `gligen_phrase_embeds`) and use `output_type="latent"`, or inject `text_encoder`/`tokenizer`/`vae`
-callables with the reference's interfaces.
+CLIP text encoding and VAE decoding (§8f) run on the same kernels (`lvd_amd.text_encoder.HipCLIPTextEncoder`, `lvd_amd.vae.HipVAEDecoder`)
+when their state_dicts are injected as `text_encoder=` / `vae=`; without them pass `prompt_embeds` / `negative_prompt_embeds` (and, for
+GLIGEN, `gligen_phrase_embeds`) and use `output_type="latent"`.  The CLIP BPE tokenizer stays an injected callable (its vocabulary files
+are not shipped in this image).
 """
 import warnings
 from dataclasses import dataclass
