@@ -20,7 +20,7 @@ def total(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     last = max((i for i, r in enumerate(rows) if "silu_kernel" in r["Kernel_Name"]), default=-1)
     rows = rows[last + 1:]
-    kernels = sorted({r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "") for r in rows})
+    kernels = sorted({r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for r in rows})
     t = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows) / 1e3 / reps
     return sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / reps, kernels, t
 
