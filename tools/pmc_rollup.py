@@ -12,9 +12,28 @@ import sys
 path = sys.argv[1]
 want = sys.argv[2] if len(sys.argv) > 2 else ""
 rows = collections.OrderedDict()
-for r in csv.DictReader(open(path)):
+allrows = list(csv.DictReader(open(path)))
+# tools/gemm_pmc.py launches a silu marker kernel between a shape's first (autotuning) call and its measured calls: dispatches between a
+# shape's first launch and its marker are tuning trials and are dropped
+marks = sorted({int(r["Dispatch_Id"]) for r in allrows if "silu_kernel" in r["Kernel_Name"]})
+rnd_ids = sorted({int(r["Dispatch_Id"]) for r in allrows if "distribution_" in r["Kernel_Name"] or "elementwise" in r["Kernel_Name"]})
+
+
+def measured(d):
+    if not marks:
+        return True
+    prev_marks = [m for m in marks if m < d]
+    if not prev_marks:
+        return False
+    later_inputs = [x for x in rnd_ids if prev_marks[-1] < x < d]  # a new shape's input generation after the marker: tuning again
+    return not later_inputs
+
+
+for r in allrows:
     name = r["Kernel_Name"]
     if want and want not in name:
+        continue
+    if not measured(int(r["Dispatch_Id"])):
         continue
     key = r["Dispatch_Id"]
     d = rows.setdefault(key, {"name": name, "grid": int(r["Grid_Size"]), "t": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3})
