@@ -474,7 +474,7 @@ def test_conv_halo(variant, n, cin, cout, h, wd):
 
 @pytest.mark.parametrize("variant", [41, 45, 47])
 @pytest.mark.parametrize("B,Fr,hw,cin,cout", [(2, 24, 45, 64, 320), (1, 24, 100, 96, 160), (3, 5, 12, 32, 128), (1, 16, 1024, 64, 96),
-                                              (2, 2, 300, 128, 320), (1, 24, 21, 320, 640)])
+                                              (2, 2, 300, 128, 320), (1, 24, 21, 320, 640), (1, 100, 7, 32, 160), (2, 256, 3, 64, 128)])
 def test_tconv_halo(variant, B, Fr, hw, cin, cout):
     """LDS-resident temporal conv (conv_halo.hip, tile = 512/F pixels x all frames): pixel blocks that do not divide HW, several
     clips, frame counts that do not divide 512, bias + residual epilogue, split-K slabs through the row map, determinism."""

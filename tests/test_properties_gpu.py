@@ -49,6 +49,34 @@ def test_conv_and_tconv_delta_kernels_are_identities():
     assert torch.equal(out[:, :-1], xr[:, 1:]) and out[:, -1].abs().max() == 0
 
 
+@pytest.mark.parametrize("variant", [41, 45, 47])
+def test_halo_conv_every_tap_is_a_shift_full_rows(variant):
+    """LDS-resident im2col kernels at the headline size: a one-hot tap turns the conv into a shift of the token matrix with zero
+    padding at the image borders — bit-exact for all nine taps (halo rows, validity masks, tiles that straddle images), and for all
+    three taps of the temporal conv (frame -1 / F padding, pixel blocks that do not divide HW)."""
+    C = 320
+    x = rnd(ROWS, C, seed=5).bfloat16()
+    xi = x.reshape(B * FR, H, W, C)
+    eye = torch.eye(C, device=DEV)
+    for t in range(9):
+        w = torch.zeros(C, 9, C, device=DEV)
+        w[:, t] = eye
+        out = ops.gemm(x, w.reshape(C, 9 * C).bfloat16(), mode=ops.A_CONV3X3, conv=ops.ConvGeom(H, W, H, W), variant=variant).reshape(B * FR, H, W, C)
+        dy, dx = t // 3 - 1, t % 3 - 1
+        want = torch.zeros_like(xi)
+        want[:, max(0, -dy):H - max(0, dy), max(0, -dx):W - max(0, dx)] = xi[:, max(0, dy):H + min(0, dy), max(0, dx):W + min(0, dx)]
+        assert torch.equal(out, want), f"variant {variant}, tap {t}"
+    xr = x.reshape(B, FR, H * W, C)
+    for t in range(3):
+        w = torch.zeros(C, 3, C, device=DEV)
+        w[:, t] = eye
+        out = ops.gemm(x, w.reshape(C, 3 * C).bfloat16(), mode=ops.A_TCONV3, frames=FR, hw=H * W, variant=variant).reshape(B, FR, H * W, C)
+        d = t - 1
+        want = torch.zeros_like(xr)
+        want[:, max(0, -d):FR - max(0, d)] = xr[:, max(0, d):FR + min(0, d)]
+        assert torch.equal(out, want), f"variant {variant}, temporal tap {t}"
+
+
 def test_attention_rows_are_stochastic_full_sequence():
     heads, hw = 5, H * W
     C = heads * 64
