@@ -100,7 +100,7 @@ class GemmTimer:
         return agg
 
 
-def cpu_baseline(sd_cpu, cfg, budget_s=45.0):
+def cpu_baseline(sd_cpu, cfg, budget_s=25.0):
     """fp32 oracle (restatement of the reference, oracle/) on the host cores, three bounded legs:
       A. BASELINE config 0 end to end: 256x144x8 (latent 18x32), DPM-Solver++ CFG sampling loop, 10 steps (stops early when
          the leg's time budget is spent; the steps are identical work, the per-step time is what is reported);
