@@ -182,10 +182,12 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     if need.value:
         ws = _splitk_workspace(a1.device, need.value)  # one grow-only buffer per device, shared by all launches of the stream
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"] and not torch.cuda.is_current_stream_capturing():
+    if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"]:
         key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample) if conv is not None else None, int(out_fp32),
                res is not None, bool(accumulate))
-        variant = _gemm_choice.get(key) or _tune_gemm(p, key, out)
+        variant = _gemm_choice.get(key) or 0
+        if variant == 0 and not torch.cuda.is_current_stream_capturing():  # a capture replays what a warm-up run has tuned
+            variant = _tune_gemm(p, key, out)
     p.variant = variant
     _launch_gemm(p)
     return out
