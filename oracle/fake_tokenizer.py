@@ -2,6 +2,7 @@
 Same call surface the DSL front-end uses: tokenizer([text], padding=..., max_length=77, return_tensors="np")["input_ids"],
 _convert_id_to_token, eos_token.  Words and punctuation marks are separate tokens, as in CLIP's BPE for common words."""
 import re
+import zlib
 
 import numpy as np
 
@@ -15,9 +16,14 @@ class FakeTokenizer:
         self.inv = {0: self.bos_token, 1: self.eos_token}
 
     def _id(self, tok):
+        # a function of the token alone (not of the order in which texts were seen): two processes that tokenize different subsets of a
+        # prompt list agree on every id, as a real vocabulary does
         if tok not in self.vocab:
-            self.vocab[tok] = len(self.vocab)
-            self.inv[self.vocab[tok]] = tok
+            i = 2 + zlib.crc32(tok.encode()) % 49000
+            while i in self.inv and self.inv[i] != tok:
+                i += 1
+            self.vocab[tok] = i
+            self.inv[i] = tok
         return self.vocab[tok]
 
     def __call__(self, texts, padding="do_not_pad", max_length=77, return_tensors="np", **kw):

@@ -94,3 +94,63 @@ def test_generate_cli_resume_and_seed_rule(tmp_path, monkeypatch):
     assert generate.main(argv) == 0  # resumed: both repeats exist
     with pytest.raises(ValueError):
         generate.main([a if a != "24" else "16" for a in argv])  # zeroscope with < 24 frames is refused like in the reference
+
+
+_DRIVER = '''
+import sys
+sys.path.insert(0, {repo!r})
+import lvd_amd  # noqa: F401
+import generate
+from lvd_amd.generation import _common
+from lvd_amd.weights import UNetConfig, synthetic_state_dict
+from oracle.fake_tokenizer import FakeClipTokenizer, FakeTextEncoder, fake_vae_decode
+SMALL = {small!r}
+_common.configure(state_dict=synthetic_state_dict(UNetConfig(**SMALL), seed=0), unet_config=dict(SMALL), tokenizer=FakeClipTokenizer(),
+                  text_encoder=FakeTextEncoder(64), vae=fake_vae_decode)
+n = generate.main(sys.argv[1:])
+print("GENERATED", n, flush=True)
+'''
+
+
+def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
+    """generate.py under torch.distributed.run, two ranks (both on this one GPU, gloo for the end-of-run tally): every rank binds a
+    device, takes the prompts `sharding.owns` gives it, and — with the GEMM autotune table of the single-process run loaded — writes
+    bit-identical videos (global prompt index -> seed, same tile geometry per shape in every process)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases, seen = [], set()
+    for c in CASES:  # four distinct prompts (a repeated prompt would consume a second cache entry)
+        if c["prompt"] not in seen and len(cases) < 4:
+            seen.add(c["prompt"])
+            cases.append(c)
+    cache_dir = tmp_path / "cache"
+    cache_dir.mkdir()
+    (cache_dir / "cache_shardtest_v0.1_gpt-4-1106-preview.json").write_text(json.dumps({c["prompt"].strip().rstrip("."): [c["response"]] for c in cases}))
+    (tmp_path / "prompts.txt").write_text("\n".join(c["prompt"] for c in cases) + "\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(_DRIVER.format(repo=repo, small=SMALL))
+    table = tmp_path / "gemm_table.json"
+
+    def argv(out):
+        return ["--model", "gpt-4", "--run-model", "lvd_zeroscope", "--prompt-type", "shardtest", "--prompts-file", str(tmp_path / "prompts.txt"),
+                "--template_version", "v0.1", "--num_frames", "24", "--num_inference_steps", "3", "--max_index_step", "1", "--max_iter", "1",
+                "--repeats", "1", "--force_run_ind", "0", "--cache-dir", str(cache_dir), "--img-root", str(tmp_path / out),
+                "--gemm_autotune_table", str(table)]
+
+    env = dict(os.environ, LVD_DIST_BACKEND="gloo", PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, str(driver)] + argv("one"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert one.returncode == 0 and "GENERATED 4" in one.stdout, one.stdout[-2000:] + one.stderr[-2000:]
+    assert table.exists()
+    port = 29600 + os.getpid() % 300
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(driver)] + argv("two"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    assert two.stdout.count("GENERATED 2") == 2, two.stdout[-2000:]  # two prompts per rank
+    root = "imgs_shardtest_templatev0.1_lvd_zeroscope/run0"
+    for i in range(4):
+        a = joblib.load(tmp_path / "one" / root / str(i) / "video_0.joblib")
+        b = joblib.load(tmp_path / "two" / root / str(i) / "video_0.joblib")
+        assert a.shape == (24, 320, 576, 3) and np.array_equal(a, b), f"prompt {i} differs between the sharded and the single-process run"
