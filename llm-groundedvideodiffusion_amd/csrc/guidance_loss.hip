@@ -124,46 +124,70 @@ __global__ void ca_com_kernel(const lvd_ca_select_params p) {
 }
 
 // ------------------------------------------------------------------------------------ 2b. select
-// Exact k-th largest of 44-bit keys (value bits << 12 | (4095 - index)) among the entries with flag==want.
-// Returns the key of the k-th largest; entries with key >= result are the top-k set.
-LVD_DEV unsigned long long radix_select(const float* vals, const unsigned char* flag, unsigned char want, int n, int k,
-                                        unsigned int* hist, unsigned long long* sh) {
-  unsigned long long prefix = 0, maskbits = 0;
-  int need = k;
+// Exact k-th largest of 44-bit keys (value bits << 12 | (4095 - index)), for the entries inside the box (flag 1, k = k1) and outside
+// it (flag 0, k = k0) at once: six 8-bit passes, both histograms built in the same sweep, and the bin that holds the k-th largest found
+// by a 256-thread suffix scan (one bin per thread, top bin first) instead of a serial walk over the bins.  thr[w] = key of the k-th
+// largest of class w (entries with key >= thr[w] are its top-k set); a class with k <= 0 or no members keeps ~0 ("nothing selected").
+// blockDim.x must be 256.
+LVD_DEV void radix_select2(const float* vals, const unsigned char* flag, int n, int k0, int k1, bool on0, bool on1,
+                           unsigned int (*hist)[256], int (*sh)[2], int (*wtot)[4], unsigned long long thr[2]) {
+  unsigned long long prefix[2] = {0, 0}, maskbits = 0;
+  int need[2] = {k0, k1};
+  const bool on[2] = {on0, on1};
+  const int tb = threadIdx.x;
   for (int pass = 5; pass >= 0; --pass) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    hist[0][tb] = 0;
+    hist[1][tb] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      if (flag[i] != want) continue;
-      unsigned long long key = ((unsigned long long)__float_as_uint(vals[i]) << 12) | (unsigned)(4095 - i);
-      if ((key & maskbits) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255], 1u);
+    for (int i = tb; i < n; i += 256) {
+      const int w = flag[i];
+      if (!on[w]) continue;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(vals[i]) << 12) | (unsigned)(4095 - i);
+      if ((key & maskbits) == prefix[w]) atomicAdd(&hist[w][(key >> (8 * pass)) & 255], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int b = 255, rem = need;
-      for (; b > 0; --b) {
-        int c = (int)hist[b];
-        if (c >= rem) break;
-        rem -= c;
+    int c[2], incl[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      c[w] = (int)hist[w][255 - tb];
+      incl[w] = c[w];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl[w], o, 64);
+        if ((tb & 63) >= o) incl[w] += v;
       }
-      sh[0] = (unsigned long long)b;
-      sh[1] = (unsigned long long)rem;
+      if ((tb & 63) == 63) wtot[w][tb >> 6] = incl[w];
     }
     __syncthreads();
-    prefix |= sh[0] << (8 * pass);
-    maskbits |= 0xffull << (8 * pass);
-    need = (int)sh[1];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      for (int q = 0; q < (tb >> 6); ++q) incl[w] += wtot[w][q];
+      const int excl = incl[w] - c[w];
+      // the first bin from the top whose running count reaches `need` (bin 0 takes whatever is left, as the serial walk did)
+      if ((incl[w] >= need[w] && excl < need[w]) || (tb == 255 && incl[w] < need[w])) {
+        sh[w][0] = 255 - tb;
+        sh[w][1] = need[w] - excl;
+      }
+    }
     __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      prefix[w] |= (unsigned long long)sh[w][0] << (8 * pass);
+      need[w] = sh[w][1];
+    }
+    maskbits |= 0xffull << (8 * pass);
   }
-  return prefix;
+  thr[0] = on0 ? prefix[0] : ~0ull;
+  thr[1] = on1 ? prefix[1] : ~0ull;
 }
 
 __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_params p) {
   extern __shared__ unsigned char smem[];
   float* vals = reinterpret_cast<float*>(smem);                         // [P]
   unsigned char* flag = smem + (size_t)p.P * 4;                         // [P] 1 = inside the box
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned long long sh[2];
+  __shared__ unsigned int hist[2][256];
+  __shared__ int sh[2][2];
+  __shared__ int wtot[2][4];
   __shared__ float red[8];
 
   const int b = blockIdx.x;
@@ -189,8 +213,10 @@ __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_para
   unsigned long long thr_fg = ~0ull, thr_bg = ~0ull;  // "nothing selected"
   const bool ratio = p.use_ratio_loss != 0;
   if (!ratio) {
-    if (nmask > 0) thr_fg = radix_select(vals, flag, 1, p.P, kfg, hist, sh);
-    if (p.P - nmask > 0) thr_bg = radix_select(vals, flag, 0, p.P, kbg, hist, sh);
+    unsigned long long thr[2];
+    radix_select2(vals, flag, p.P, kbg, kfg, p.P - nmask > 0, nmask > 0, hist, sh, wtot, thr);
+    thr_bg = thr[0];
+    thr_fg = thr[1];
   }
   // ratio-based energy (utils/guidance.py:312-323): act = sum(A*mask) / (sum(A) + eps); loss = mean over heads of (1 - act)^2
   float r_in = 0.f, r_out = 0.f, ratio_loss = 0.f;  // dL/dA[p] = r_in inside the box, r_out outside
