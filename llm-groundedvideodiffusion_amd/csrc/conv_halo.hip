@@ -333,32 +333,7 @@ __global__ void tap_reduce_kernel(const lvd_gemm_params p, const int tile_base, 
     const int m = geo.out_row(l);
     const int n = tn * BN + q * 4;
     if (m >= p.M || n >= p.N) continue;
-    const float* s0 = p.ws + ((long)t * HALO_BM + l) * BN + q * 4;
-    const long sstride = (long)ntile * HALO_BM * BN;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s0);
-    for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(s0 + s * sstride);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * p.N + n);
-    v *= p.alpha;
-    if (p.res) {
-      uint2 r = ldg8(p.res + (long)m * p.ldres + n);
-      v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
-    }
-    if (p.out_fp32) {
-      float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
-      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
-      *reinterpret_cast<f32x4*>(o) = v;
-    } else {
-      lvd_bf16* o = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
-      if (p.accumulate) {
-        uint2 r = ldg8(o);
-        v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
-      }
-      uint2 w;
-      w.x = pack2bf(v[0], v[1]);
-      w.y = pack2bf(v[2], v[3]);
-      stg8(o, w);
-    }
+    splitk_reduce_quad(p, p.ws + ((long)t * HALO_BM + l) * BN + q * 4, (long)ntile * HALO_BM * BN, m, n);
   }
 }
 

@@ -402,3 +402,55 @@ inline int lvd_splitk_plan(long tiles, int K, int slots, int slab_cost, long* co
 }
 
 }  // namespace
+
+// Slab reduction tail shared by the K-split reduce kernels (gemm_ring.hip, conv_halo.hip): out[m, n..n+3] = epilogue(sum over slices).
+// Every load of a quad is issued before the first use: the slices four at a time, the side operands (bias, temb row-bias, residual,
+// accumulate target) unconditionally from a harmless address when absent — a load inside a (uniform) branch is waited for inside
+// that branch, and one memory round trip per slice and per operand is what these small kernels used to cost (ks + 3 round trips).
+// The summation order is the sequential one: ((s0 + s1) + s2) + ...
+LVD_DEV void splitk_reduce_quad(const lvd_gemm_params& p, const float* s0, long sstride, int m, int n) {
+  const float* safe = p.ws;
+  const float* bp = p.bias ? p.bias + n : safe;
+  const float* rbp = p.rowbias ? p.rowbias + (long)(m / (p.rows_per_sample > 0 ? p.rows_per_sample : 1)) * p.N + n : safe;
+  const lvd_bf16* rp = p.res ? p.res + (long)m * p.ldres + n : reinterpret_cast<const lvd_bf16*>(safe);
+  float* of = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
+  lvd_bf16* ob = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;
+  const bool acc32 = p.accumulate && p.out_fp32, acc16 = p.accumulate && !p.out_fp32;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+  const f32x4 rbv = *reinterpret_cast<const f32x4*>(rbp);
+  const uint2 rv = ldg8(rp);
+  const f32x4 av32 = *reinterpret_cast<const f32x4*>(acc32 ? of : safe);
+  const uint2 av16 = ldg8(acc16 ? ob : reinterpret_cast<const lvd_bf16*>(safe));
+  f32x4 v = *reinterpret_cast<const f32x4*>(s0);
+  int s = 1;
+  for (; s + 3 < p.ksplit; s += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + (long)s * sstride);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + (long)(s + 1) * sstride);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(s0 + (long)(s + 2) * sstride);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(s0 + (long)(s + 3) * sstride);
+    v += a; v += b; v += c; v += d;
+  }
+  {  // up to three left: clamped slice index, masked value
+    const int last = p.ksplit - 1;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + (long)min(s, last) * sstride);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + (long)min(s + 1, last) * sstride);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(s0 + (long)min(s + 2, last) * sstride);
+    if (s < p.ksplit) v += a;
+    if (s + 1 < p.ksplit) v += b;
+    if (s + 2 < p.ksplit) v += c;
+  }
+  if (p.bias) v += bv;
+  if (p.rowbias) v += rbv;
+  v *= p.alpha;
+  if (p.res) { v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y); }
+  if (p.out_fp32) {
+    if (p.accumulate) v += av32;
+    *reinterpret_cast<f32x4*>(of) = v;
+  } else {
+    if (p.accumulate) { v[0] += bflo(av16.x); v[1] += bfhi(av16.x); v[2] += bflo(av16.y); v[3] += bfhi(av16.y); }
+    uint2 w;
+    w.x = pack2bf(v[0], v[1]);
+    w.y = pack2bf(v[2], v[3]);
+    stg8(ob, w);
+  }
+}
