@@ -30,6 +30,7 @@ constexpr int VT_PITCH = 18;  // dwords per d-row of the transposed V tile (16 k
 
 __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p) {
   __shared__ uint32_t vt[64 * VT_PITCH];
+  __shared__ uint4 qk[32 * 8];  // Q tile, then one K tile at a time: [row][16-byte chunk ^ (row & 7)]
 
   const int lane = threadIdx.x;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -45,11 +46,23 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
   const int qic = min(qi, p.sq - 1);
   const long qrow = qbase + (long)qic * p.q_step;
 
+  // Q and every K tile reach their MFMA fragments through a 4 KB LDS tile: the global loads then cover whole 128-byte head rows
+  // (eight lanes per row) instead of 32 bytes of 32 different rows per instruction — four instructions re-touching the same lines,
+  // which at 16 waves per CU do not survive in the L1.  XOR chunk swizzle: conflict-free ds_read_b128 in the fragment layout.
+  const int sr = lane >> 3, scn = lane & 7;  // staging role: row sr (+8 per instruction), 16-byte chunk scn
+  auto frag = [&](int ks) { return as_bf16x8(qk[l31 * 8 + ((ks * 2 + hi) ^ (l31 & 7))]); };
   bf16x8 qf[4];
   {
-    const lvd_bf16* qp = p.q + qrow * p.ldq + h * 64 + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + sr;
+      const long row = qbase + (long)min(qt * 32 + r, p.sq - 1) * p.q_step;
+      qk[r * 8 + (scn ^ (r & 7))] = ldg16(p.q + row * p.ldq + h * 64 + scn * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag(ks);
+    __syncthreads();
   }
 
   f32x16 o0, o1;
@@ -66,14 +79,18 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
 #pragma unroll
     for (int e = 0; e < 16; ++e) st[e] = 0.f;
     {
-      int kk = min(kt * 32 + l31, skv_tot - 1);
-      const lvd_bf16* kp = (kk < p.skv) ? p.k + (kvbase + (long)kk * p.kv_step) * p.ldk
-                                        : p.k2 + (kv2base + (long)(kk - p.skv) * p.kv2_step) * p.ldk2;
-      kp += h * 64 + hi * 8;
+      uint4 kr[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 kf = as_bf16x8(ldg16(kp + ks * 16));
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+      for (int it = 0; it < 4; ++it) {
+        const int kk = min(kt * 32 + it * 8 + sr, skv_tot - 1);
+        const lvd_bf16* kp = (kk < p.skv) ? p.k + (kvbase + (long)kk * p.kv_step) * p.ldk
+                                          : p.k2 + (kv2base + (long)(kk - p.skv) * p.kv2_step) * p.ldk2;
+        kr[it] = ldg16(kp + h * 64 + scn * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + sr;
+        qk[r * 8 + (scn ^ (r & 7))] = kr[it];
       }
     }
     // ---- V tile -> LDS, transposed: vt[d][key pair]
@@ -98,6 +115,8 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ks), qf[ks], st, 0, 0, 0);
 
     // ---- online softmax (lane-local over this lane's 16 keys + partner half).  The running max is only raised when
     // some query's tile maximum exceeds it by more than 2^RESCALE_THR (exact: p stays <= 2^THR, l and O share the scale)
@@ -158,9 +177,10 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
 
   float ltot = lsum + __shfl_xor(lsum, 32, 64);
   float inv = 1.f / ltot;
-  if (qi < p.sq) {
-    const long orow = qbase + (long)qi * p.q_step;
-    lvd_bf16* op = p.o + orow * p.ldo + h * 64 + 4 * hi;
+  // O tile back through the LDS tile (the loop's last barrier retired every read of it): whole 128-byte head rows per store
+  // instruction instead of 16 bytes of 32 different rows
+  {
+    uint2* ot = reinterpret_cast<uint2*>(qk);  // [query][16-byte chunk ^ (query & 7)], two uint2 per chunk
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       uint2 w0, w1;
@@ -168,11 +188,17 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
       w0.y = pack2bf(o0[rq * 4 + 2] * inv, o0[rq * 4 + 3] * inv);
       w1.x = pack2bf(o1[rq * 4 + 0] * inv, o1[rq * 4 + 1] * inv);
       w1.y = pack2bf(o1[rq * 4 + 2] * inv, o1[rq * 4 + 3] * inv);
-      stg8(op + 8 * rq, w0);
-      stg8(op + 32 + 8 * rq, w1);
+      ot[(l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi] = w0;        // d = 8 rq + 4 hi .. +3
+      ot[(l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi] = w1;  // d = 32 + 8 rq + 4 hi .. +3
     }
-    if (p.lse && hi == 0) p.lse[((long)s * p.heads + h) * p.sq + qi] = (m + log2f(ltot)) * 0.6931471805599453f;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + sr, q = qt * 32 + r;
+      if (q < p.sq) stg16(p.o + (qbase + (long)q * p.q_step) * p.ldo + h * 64 + scn * 8, qk[r * 8 + (scn ^ (r & 7))]);
+    }
   }
+  if (qi < p.sq && p.lse && hi == 0) p.lse[((long)s * p.heads + h) * p.sq + qi] = (m + log2f(ltot)) * 0.6931471805599453f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -340,7 +366,7 @@ extern "C" int lvdhip_attention_fwd(const lvd_attn_params* p, void* stream) {
   LVD_CHECK(p && p->q && p->k && p->v && p->o, "attention_fwd: null pointer");
   LVD_CHECK(p->sq > 0 && p->skv > 0 && p->samples > 0 && p->heads > 0, "attention_fwd: bad sizes");
   LVD_CHECK(p->skv2 == 0 || (p->k2 && p->v2), "attention_fwd: second KV segment pointers missing");
-  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 4 == 0, "attention_fwd: leading dims must be multiples of 8");
+  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 8 == 0, "attention_fwd: leading dims must be multiples of 8");
   LVD_CHECK(p->heads <= 65535, "attention_fwd: too many heads");
   LVD_CHECK(p->q_ninner > 0 && p->kv_ninner > 0, "attention_fwd: ninner must be > 0");
   static int force = -1;
