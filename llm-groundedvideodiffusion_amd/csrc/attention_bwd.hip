@@ -57,12 +57,43 @@ LVD_DEV float dot8(uint4 a, uint4 b) {
          bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
 
+// Row-major 32-row x 128-byte LDS tile with an XOR chunk swizzle ([row][16-byte chunk ^ (row & 7)]): global loads and stores cover
+// whole head rows (eight lanes per row) and the MFMA fragments are conflict-free ds_read_b128.  sr = lane >> 3 (row within an
+// 8-row instruction), scn = lane & 7 (chunk).
+LVD_DEV bf16x8 tile_frag(const uint4* tile, int l31, int hi, int ks) { return as_bf16x8(tile[l31 * 8 + ((ks * 2 + hi) ^ (l31 & 7))]); }
+LVD_DEV void tile_put(uint4* tile, const uint4 v[4], int sr, int scn) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 8 + sr;
+    tile[r * 8 + (scn ^ (r & 7))] = v[it];
+  }
+}
+// transposed [64 d][32 rows] staging of a tile that already sits row-major in LDS (instead of a second trip to global memory)
+LVD_DEV void stage_transposed_from_tile(uint32_t* lds, const uint4* tile, int vj, int vdc) {
+  const int r0 = 2 * vj, r1 = 2 * vj + 1;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int c = vdc + 4 * half, d0 = c * 8;
+    const uint4 a = tile[r0 * 8 + (c ^ (r0 & 7))];
+    const uint4 b = tile[r1 * 8 + (c ^ (r1 & 7))];
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lds[(d0 + 2 * e) * TP + vj] = (aw[e] & 0xffffu) | (bw[e] << 16);
+      lds[(d0 + 2 * e + 1) * TP + vj] = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- dQ
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_params bp) {
   __shared__ uint32_t kt_lds[64 * TP];
+  __shared__ uint4 ta[32 * 8], tb[32 * 8];  // Q then K tiles / dO then V tiles (row-major, swizzled)
+  __shared__ float dl[32];
   const lvd_attn_params& p = bp.f;
   const int lane = threadIdx.x;
   const int l31 = lane & 31, hi = lane >> 5;
+  const int sr = lane >> 3, scn = lane & 7;
   const int nqt = (p.sq + 31) >> 5;
   const int s = blockIdx.x / nqt, qt = blockIdx.x - s * nqt, h = blockIdx.y;
   const long qbase = base_row(s, p.q_ninner, p.q_os, p.q_is);
@@ -70,27 +101,37 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
 
   const int qi = qt * 32 + l31;
   const int qic = min(qi, p.sq - 1);
-  const long qrow = qbase + (long)qic * p.q_step;
 
+  // Q, dO, O as whole rows; delta = rowsum(dO . O) is reduced over the eight lanes of a row before anything is transposed
   bf16x8 qf[4], dof[4];
-  float delta = 0.f;
   {
-    const lvd_bf16* qp = p.q + qrow * p.ldq + h * 64 + hi * 8;
-    const lvd_bf16* dp = bp.d_o + qrow * bp.lddo + h * 64 + hi * 8;
-    const lvd_bf16* op = p.o + qrow * p.ldo + h * 64 + hi * 8;
+    uint4 vq[4], vd[4];
+    float part[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
-      uint4 d4 = ldg16(dp + ks * 16);
-      dof[ks] = as_bf16x8(d4);
-      delta += dot8(d4, ldg16(op + ks * 16));
+    for (int it = 0; it < 4; ++it) {
+      const long row = qbase + (long)min(qt * 32 + it * 8 + sr, p.sq - 1) * p.q_step;
+      vq[it] = ldg16(p.q + row * p.ldq + h * 64 + scn * 8);
+      vd[it] = ldg16(bp.d_o + row * bp.lddo + h * 64 + scn * 8);
+      part[it] = dot8(vd[it], ldg16(p.o + row * p.ldo + h * 64 + scn * 8));
     }
+    tile_put(ta, vq, sr, scn);
+    tile_put(tb, vd, sr, scn);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float d = part[it];
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      if (scn == 0) dl[it * 8 + sr] = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = tile_frag(ta, l31, hi, ks); dof[ks] = tile_frag(tb, l31, hi, ks); }
   }
-  delta += __shfl_xor(delta, 32, 64);
+  const float delta = dl[l31];
   const long sidx = ((long)s * p.heads + h) * p.sq + qic;
   if (hi == 0 && qi < p.sq) bp.delta[sidx] = delta;
   const float lse2 = p.lse[sidx] * 1.4426950408889634f;
   const float sc = p.scale * 1.4426950408889634f;
+  __syncthreads();
 
   f32x16 dq0, dq1;
 #pragma unroll
@@ -102,21 +143,23 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
 #pragma unroll
     for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = 0.f; }
     {
-      int kk = min(kt * 32 + l31, p.skv - 1);
-      long krow = kvbase + (long)kk * p.kv_step;
-      const lvd_bf16* kp = p.k + krow * p.ldk + h * 64 + hi * 8;
-      const lvd_bf16* vp = p.v + krow * p.ldv + h * 64 + hi * 8;
+      uint4 vk[4], vv[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ldg16(kp + ks * 16)), qf[ks], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ldg16(vp + ks * 16)), dof[ks], dpt, 0, 0, 0);
+      for (int it = 0; it < 4; ++it) {
+        const long krow = kvbase + (long)min(kt * 32 + it * 8 + sr, p.skv - 1) * p.kv_step;
+        vk[it] = ldg16(p.k + krow * p.ldk + h * 64 + scn * 8);
+        vv[it] = ldg16(p.v + krow * p.ldv + h * 64 + scn * 8);
       }
+      tile_put(ta, vk, sr, scn);
+      tile_put(tb, vv, sr, scn);
     }
-    {
-      int k0 = min(kt * 32 + 2 * vj, p.skv - 1), k1 = min(kt * 32 + 2 * vj + 1, p.skv - 1);
-      stage_transposed(kt_lds, p.k + (kvbase + (long)k0 * p.kv_step) * p.ldk + h * 64,
-                       p.k + (kvbase + (long)k1 * p.kv_step) * p.ldk + h * 64, vj, vdc);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(ta, l31, hi, ks), qf[ks], st, 0, 0, 0);
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(tb, l31, hi, ks), dof[ks], dpt, 0, 0, 0);
     }
+    stage_transposed_from_tile(kt_lds, ta, vj, vdc);
     __syncthreads();
     float ds[16];
 #pragma unroll
@@ -134,8 +177,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
     __syncthreads();
   }
 
-  if (qi < p.sq) {
-    lvd_bf16* op = bp.dq + (qbase + (long)qi * p.q_step) * bp.lddq + h * 64 + 4 * hi;
+  {  // dQ tile back through LDS: whole rows per store instruction
+    uint2* ot = reinterpret_cast<uint2*>(ta);
     const float f = p.scale;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
@@ -144,8 +187,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
       w0.y = pack2bf(dq0[rq * 4 + 2] * f, dq0[rq * 4 + 3] * f);
       w1.x = pack2bf(dq1[rq * 4 + 0] * f, dq1[rq * 4 + 1] * f);
       w1.y = pack2bf(dq1[rq * 4 + 2] * f, dq1[rq * 4 + 3] * f);
-      stg8(op + 8 * rq, w0);
-      stg8(op + 32 + 8 * rq, w1);
+      ot[(l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi] = w0;
+      ot[(l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi] = w1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + sr, q = qt * 32 + r;
+      if (q < p.sq) stg16(bp.dq + (qbase + (long)q * p.q_step) * bp.lddq + h * 64 + scn * 8, ta[r * 8 + (scn ^ (r & 7))]);
     }
   }
 }
@@ -511,7 +560,7 @@ extern "C" int lvdhip_attention_bwd(const lvd_attn_bwd_params* bp, void* stream)
   LVD_CHECK(p->q && p->k && p->v && p->o && p->lse && bp->d_o && bp->dq && bp->delta, "attention_bwd: null pointer");
   LVD_CHECK(p->skv2 == 0, "attention_bwd: second KV segment is forward-only (the guidance pass never has GLIGEN tokens)");
   LVD_CHECK((bp->dk == nullptr) == (bp->dv == nullptr), "attention_bwd: dk and dv must both be given or both be NULL");
-  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 8 == 0 && bp->lddo % 8 == 0 && bp->lddq % 4 == 0,
+  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 8 == 0 && bp->lddo % 8 == 0 && bp->lddq % 8 == 0,
             "attention_bwd: leading dims must be multiples of 8");
   hipStream_t s = (hipStream_t)stream;
   static int force = -1;
