@@ -203,26 +203,31 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
 __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_params bp) {
   __shared__ uint32_t qt_lds[64 * TP];
   __shared__ uint32_t dot_lds[64 * TP];
+  __shared__ uint4 ta[32 * 8], tb[32 * 8];  // K then Q tiles / V then dO tiles (row-major, swizzled), dK / dV on the way out
   const lvd_attn_params& p = bp.f;
   const int lane = threadIdx.x;
   const int l31 = lane & 31, hi = lane >> 5;
+  const int sr = lane >> 3, scn = lane & 7;
   const int nkt = (p.skv + 31) >> 5;
   const int s = blockIdx.x / nkt, ktile = blockIdx.x - s * nkt, h = blockIdx.y;
   const long qbase = base_row(s, p.q_ninner, p.q_os, p.q_is);
   const long kvbase = base_row(s, p.kv_ninner, p.kv_os, p.kv_is);
 
-  const int ki = ktile * 32 + l31;
-  const int kic = min(ki, p.skv - 1);
-  const long krow = kvbase + (long)kic * p.kv_step;
   bf16x8 kf[4], vf[4];
   {
-    const lvd_bf16* kp = p.k + krow * p.ldk + h * 64 + hi * 8;
-    const lvd_bf16* vp = p.v + krow * p.ldv + h * 64 + hi * 8;
+    uint4 vk[4], vv[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = as_bf16x8(ldg16(kp + ks * 16));
-      vf[ks] = as_bf16x8(ldg16(vp + ks * 16));
+    for (int it = 0; it < 4; ++it) {
+      const long krow = kvbase + (long)min(ktile * 32 + it * 8 + sr, p.skv - 1) * p.kv_step;
+      vk[it] = ldg16(p.k + krow * p.ldk + h * 64 + scn * 8);
+      vv[it] = ldg16(p.v + krow * p.ldv + h * 64 + scn * 8);
     }
+    tile_put(ta, vk, sr, scn);
+    tile_put(tb, vv, sr, scn);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = tile_frag(ta, l31, hi, ks); vf[ks] = tile_frag(tb, l31, hi, ks); }
+    __syncthreads();
   }
   const float sc = p.scale * 1.4426950408889634f;
   f32x16 dk0, dk1, dv0, dv1;
@@ -236,23 +241,25 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_par
 #pragma unroll
     for (int e = 0; e < 16; ++e) { sm[e] = 0.f; dpm[e] = 0.f; }
     {
-      int qq = min(qt * 32 + l31, p.sq - 1);
-      long qrow = qbase + (long)qq * p.q_step;
-      const lvd_bf16* qp = p.q + qrow * p.ldq + h * 64 + hi * 8;
-      const lvd_bf16* dp = bp.d_o + qrow * bp.lddo + h * 64 + hi * 8;
+      uint4 vq[4], vd[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        // S[query][key] = Q · K^T ; dP[query][key] = dO · V^T   (rows = queries, cols = this lane's key)
-        sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ldg16(qp + ks * 16)), kf[ks], sm, 0, 0, 0);
-        dpm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ldg16(dp + ks * 16)), vf[ks], dpm, 0, 0, 0);
+      for (int it = 0; it < 4; ++it) {
+        const long qrow = qbase + (long)min(qt * 32 + it * 8 + sr, p.sq - 1) * p.q_step;
+        vq[it] = ldg16(p.q + qrow * p.ldq + h * 64 + scn * 8);
+        vd[it] = ldg16(bp.d_o + qrow * bp.lddo + h * 64 + scn * 8);
       }
+      tile_put(ta, vq, sr, scn);
+      tile_put(tb, vd, sr, scn);
     }
-    {
-      int q0 = min(qt * 32 + 2 * vj, p.sq - 1), q1 = min(qt * 32 + 2 * vj + 1, p.sq - 1);
-      long r0 = qbase + (long)q0 * p.q_step, r1 = qbase + (long)q1 * p.q_step;
-      stage_transposed(qt_lds, p.q + r0 * p.ldq + h * 64, p.q + r1 * p.ldq + h * 64, vj, vdc);
-      stage_transposed(dot_lds, bp.d_o + r0 * bp.lddo + h * 64, bp.d_o + r1 * bp.lddo + h * 64, vj, vdc);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // S[query][key] = Q · K^T ; dP[query][key] = dO · V^T   (rows = queries, cols = this lane's key)
+      sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(ta, l31, hi, ks), kf[ks], sm, 0, 0, 0);
+      dpm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(tb, l31, hi, ks), vf[ks], dpm, 0, 0, 0);
     }
+    stage_transposed_from_tile(qt_lds, ta, vj, vdc);
+    stage_transposed_from_tile(dot_lds, tb, vj, vdc);
     __syncthreads();
     float pr[16], ds[16];
 #pragma unroll
@@ -278,21 +285,32 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_par
     __syncthreads();
   }
 
-  if (ki < p.skv) {
-    lvd_bf16* dkp = bp.dk + krow * bp.lddk + h * 64 + 4 * hi;
-    lvd_bf16* dvp = bp.dv + krow * bp.lddv + h * 64 + 4 * hi;
+  {  // dK, dV tiles back through LDS: whole rows per store instruction
+    uint2* ok = reinterpret_cast<uint2*>(ta);
+    uint2* ov = reinterpret_cast<uint2*>(tb);
     const float f = p.scale;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       uint2 w;
+      const int c0 = (l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi, c1 = (l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi;
       w.x = pack2bf(dk0[rq * 4 + 0] * f, dk0[rq * 4 + 1] * f); w.y = pack2bf(dk0[rq * 4 + 2] * f, dk0[rq * 4 + 3] * f);
-      stg8(dkp + 8 * rq, w);
+      ok[c0] = w;
       w.x = pack2bf(dk1[rq * 4 + 0] * f, dk1[rq * 4 + 1] * f); w.y = pack2bf(dk1[rq * 4 + 2] * f, dk1[rq * 4 + 3] * f);
-      stg8(dkp + 32 + 8 * rq, w);
+      ok[c1] = w;
       w.x = pack2bf(dv0[rq * 4 + 0], dv0[rq * 4 + 1]); w.y = pack2bf(dv0[rq * 4 + 2], dv0[rq * 4 + 3]);
-      stg8(dvp + 8 * rq, w);
+      ov[c0] = w;
       w.x = pack2bf(dv1[rq * 4 + 0], dv1[rq * 4 + 1]); w.y = pack2bf(dv1[rq * 4 + 2], dv1[rq * 4 + 3]);
-      stg8(dvp + 32 + 8 * rq, w);
+      ov[c1] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + sr, k = ktile * 32 + r;
+      if (k < p.skv) {
+        const long krow = kvbase + (long)k * p.kv_step;
+        stg16(bp.dk + krow * bp.lddk + h * 64 + scn * 8, ta[r * 8 + (scn ^ (r & 7))]);
+        stg16(bp.dv + krow * bp.lddv + h * 64 + scn * 8, tb[r * 8 + (scn ^ (r & 7))]);
+      }
     }
   }
 }
@@ -575,7 +593,7 @@ extern "C" int lvdhip_attention_bwd(const lvd_attn_bwd_params* bp, void* stream)
   }
   LVD_LAUNCH_CHECK();
   if (bp->dk) {
-    LVD_CHECK(bp->lddk % 4 == 0 && bp->lddv % 4 == 0, "attention_bwd: lddk/lddv");
+    LVD_CHECK(bp->lddk % 8 == 0 && bp->lddv % 8 == 0, "attention_bwd: lddk/lddv");
     if (v2) {
       dim3 gk(((p->skv + 127) / 128) * p->samples, p->heads);
       hipLaunchKernelGGL(attn_bwd_dkv_v2_kernel, gk, dim3(256), 0, s, *bp);
