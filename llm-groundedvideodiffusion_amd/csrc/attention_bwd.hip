@@ -315,6 +315,152 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_par
   }
 }
 
+// ------------------------------------------------------------------------------------------- dQ, dK, dV in one pass
+// Sequences of at most 32 queries and 32 keys (temporal attention: 24 frames): one wave owns a whole (sample, head), so the five
+// operand tiles (Q, K, V, dO, O) are read ONCE — the dQ and dK/dV kernels above each read four of them and recompute S.
+// Both orientations of the score tile are formed: S^T = K·Q^T with the query on the lane axis (softmax statistics lane-local ->
+// dS^T -> dQ), and S = Q·K^T with the key on the lane axis (-> P, dS -> dV, dK).
+__global__ __launch_bounds__(64) void attn_bwd_small_kernel(const lvd_attn_bwd_params bp) {
+  __shared__ uint4 tq[32 * 8], tk[32 * 8], tv[32 * 8], td[32 * 8];  // row-major swizzled tiles: Q, K, V, dO
+  __shared__ uint32_t xa[64 * TP], xb[64 * TP];                       // transposed: K^T, then Q^T / dO^T
+  __shared__ float dl[32], ls[32];
+  const lvd_attn_params& p = bp.f;
+  const int lane = threadIdx.x;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int sr = lane >> 3, scn = lane & 7;
+  const int s = blockIdx.x, h = blockIdx.y;
+  const long qbase = base_row(s, p.q_ninner, p.q_os, p.q_is);
+  const long kvbase = base_row(s, p.kv_ninner, p.kv_os, p.kv_is);
+  const long sbase = ((long)s * p.heads + h) * p.sq;
+  {
+    uint4 vq[4], vd[4], vk[4], vv[4];
+    float part[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long qrow = qbase + (long)min(it * 8 + sr, p.sq - 1) * p.q_step;
+      const long krow = kvbase + (long)min(it * 8 + sr, p.skv - 1) * p.kv_step;
+      vq[it] = ldg16(p.q + qrow * p.ldq + h * 64 + scn * 8);
+      vd[it] = ldg16(bp.d_o + qrow * bp.lddo + h * 64 + scn * 8);
+      vk[it] = ldg16(p.k + krow * p.ldk + h * 64 + scn * 8);
+      vv[it] = ldg16(p.v + krow * p.ldv + h * 64 + scn * 8);
+      part[it] = dot8(vd[it], ldg16(p.o + qrow * p.ldo + h * 64 + scn * 8));
+    }
+    tile_put(tq, vq, sr, scn);
+    tile_put(td, vd, sr, scn);
+    tile_put(tk, vk, sr, scn);
+    tile_put(tv, vv, sr, scn);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float d = part[it];
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      if (scn == 0) dl[it * 8 + sr] = d;
+    }
+    if (lane < 32) ls[lane] = p.lse[sbase + min(lane, p.sq - 1)] * 1.4426950408889634f;
+  }
+  __syncthreads();
+  if (lane < p.sq) bp.delta[sbase + lane] = dl[lane];
+  const float sc = p.scale * 1.4426950408889634f;
+  const int vj = lane & 15, vdc = lane >> 4;
+
+  // ---- query on the lane axis: dS^T, dQ
+  f32x16 dq0, dq1;
+  {
+    f32x16 st, dpt;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = 0.f; dq0[e] = 0.f; dq1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(tk, l31, hi, ks), tile_frag(tq, l31, hi, ks), st, 0, 0, 0);
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(tv, l31, hi, ks), tile_frag(td, l31, hi, ks), dpt, 0, 0, 0);
+    }
+    stage_transposed_from_tile(xa, tk, vj, vdc);
+    __syncthreads();
+    const float lse2 = ls[l31], delta = dl[l31];
+    float ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kidx = (e & 3) + 8 * (e >> 2) + 4 * hi;
+      const float pr = (kidx < p.skv) ? fast_exp2(st[e] * sc - lse2) : 0.f;
+      ds[e] = pr * (dpt[e] - delta);
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const bf16x8 dsf = pack8(ds + ks2 * 8);
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(xa, l31, ks2, hi), dsf, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(xa, 32 + l31, ks2, hi), dsf, dq1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- key on the lane axis: P, dS, dV, dK
+  f32x16 dk0, dk1, dv0, dv1;
+  {
+    f32x16 sm, dpm;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { sm[e] = 0.f; dpm[e] = 0.f; dk0[e] = 0.f; dk1[e] = 0.f; dv0[e] = 0.f; dv1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(tq, l31, hi, ks), tile_frag(tk, l31, hi, ks), sm, 0, 0, 0);
+      dpm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(td, l31, hi, ks), tile_frag(tv, l31, hi, ks), dpm, 0, 0, 0);
+    }
+    stage_transposed_from_tile(xa, tq, vj, vdc);
+    stage_transposed_from_tile(xb, td, vj, vdc);
+    __syncthreads();
+    float pr[16], ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qidx = (e & 3) + 8 * (e >> 2) + 4 * hi;
+      const float pe = (qidx < p.sq) ? fast_exp2(sm[e] * sc - ls[qidx]) : 0.f;
+      pr[e] = pe;
+      ds[e] = pe * (dpm[e] - dl[qidx]);
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const bf16x8 pf = pack8(pr + ks2 * 8), dsf = pack8(ds + ks2 * 8);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(xb, l31, ks2, hi), pf, dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(xb, 32 + l31, ks2, hi), pf, dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(xa, l31, ks2, hi), dsf, dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(xa, 32 + l31, ks2, hi), dsf, dk1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  {  // results through the row-major tiles: whole rows per store instruction
+    uint2* oq = reinterpret_cast<uint2*>(tq);
+    uint2* ok = reinterpret_cast<uint2*>(tk);
+    uint2* ov = reinterpret_cast<uint2*>(tv);
+    const float f = p.scale;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      uint2 w;
+      const int c0 = (l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi, c1 = (l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi;
+      w.x = pack2bf(dq0[rq * 4 + 0] * f, dq0[rq * 4 + 1] * f); w.y = pack2bf(dq0[rq * 4 + 2] * f, dq0[rq * 4 + 3] * f);
+      oq[c0] = w;
+      w.x = pack2bf(dq1[rq * 4 + 0] * f, dq1[rq * 4 + 1] * f); w.y = pack2bf(dq1[rq * 4 + 2] * f, dq1[rq * 4 + 3] * f);
+      oq[c1] = w;
+      w.x = pack2bf(dk0[rq * 4 + 0] * f, dk0[rq * 4 + 1] * f); w.y = pack2bf(dk0[rq * 4 + 2] * f, dk0[rq * 4 + 3] * f);
+      ok[c0] = w;
+      w.x = pack2bf(dk1[rq * 4 + 0] * f, dk1[rq * 4 + 1] * f); w.y = pack2bf(dk1[rq * 4 + 2] * f, dk1[rq * 4 + 3] * f);
+      ok[c1] = w;
+      w.x = pack2bf(dv0[rq * 4 + 0], dv0[rq * 4 + 1]); w.y = pack2bf(dv0[rq * 4 + 2], dv0[rq * 4 + 3]);
+      ov[c0] = w;
+      w.x = pack2bf(dv1[rq * 4 + 0], dv1[rq * 4 + 1]); w.y = pack2bf(dv1[rq * 4 + 2], dv1[rq * 4 + 3]);
+      ov[c1] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + sr, c = r * 8 + (scn ^ (r & 7));
+      if (r < p.sq) stg16(bp.dq + (qbase + (long)r * p.q_step) * bp.lddq + h * 64 + scn * 8, tq[c]);
+      if (r < p.skv) {
+        const long krow = kvbase + (long)r * p.kv_step;
+        stg16(bp.dk + krow * bp.lddk + h * 64 + scn * 8, tk[c]);
+        stg16(bp.dv + krow * bp.lddv + h * 64 + scn * 8, tv[c]);
+      }
+    }
+  }
+}
+
 // ===============================================================================================================
 // v2 kernels for long self-attention sequences: 4 waves share every streamed tile through LDS (row-major copy for
 // the A-operand fragments, transposed copy for the contraction over the tile's rows), register-prefetched double
@@ -584,6 +730,12 @@ extern "C" int lvdhip_attention_bwd(const lvd_attn_bwd_params* bp, void* stream)
   static int force = -1;
   if (force < 0) { const char* e = getenv("LVD_ATTN_VARIANT"); force = e ? atoi(e) : 0; }
   const bool v2 = force == 2 || (force == 0 && p->sq >= 128 && p->skv >= 128);
+  if (!v2 && force != 1 && bp->dk && p->sq <= 32 && p->skv <= 32) {  // temporal attention: one pass for dQ, dK, dV
+    LVD_CHECK(bp->lddk % 8 == 0 && bp->lddv % 8 == 0, "attention_bwd: lddk/lddv");
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(p->samples, p->heads), dim3(64), 0, s, *bp);
+    LVD_LAUNCH_CHECK();
+    return 0;
+  }
   if (v2) {
     dim3 gq(((p->sq + 127) / 128) * p->samples, p->heads);
     hipLaunchKernelGGL(attn_bwd_dq_v2_kernel, gq, dim3(256), 0, s, *bp);

@@ -27,7 +27,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("mode", ["spatial", "spatial_long", "temporal", "cross"])
+@pytest.mark.parametrize("mode", ["spatial", "spatial_long", "temporal", "temporal_5", "temporal_32", "cross"])
 def test_attention_backward(mode):
     H = 2
     C = H * 64
@@ -37,8 +37,8 @@ def test_attention_backward(mode):
         qm = km = ops.RowMap(1, sq, 0, 1)
         perm = lambda t, L: t.reshape(S, L, H, 64).permute(0, 2, 1, 3)
         unperm = lambda t: t.permute(0, 2, 1, 3).reshape(-1, C)
-    elif mode == "temporal":
-        Bt, Fr, hw = 2, 24, 10
+    elif mode.startswith("temporal"):  # <= 32 frames: the single-pass dQ/dK/dV kernel
+        Bt, Fr, hw = 2, {"temporal": 24, "temporal_5": 5, "temporal_32": 32}[mode], 10
         S, sq, skv = Bt * hw, Fr, Fr
         rows = Bt * Fr * hw
         qm = km = ops.RowMap(hw, Fr * hw, 1, hw)
