@@ -31,9 +31,12 @@ LVD_DEV void stg8(void* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
 
 LVD_DEV bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-LVD_DEV float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// SiLU and its derivative with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (a ten-instruction sequence):
+// these run once or twice per element inside kernels that otherwise only stream bf16 rows, and every consumer rounds to bf16
+LVD_DEV float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+LVD_DEV float silu_f(float x) { return x * sigmoid_f(x); }
 LVD_DEV float silu_grad_f(float x) {
-  float s = 1.f / (1.f + __expf(-x));
+  float s = sigmoid_f(x);
   return s * (1.f + x * (1.f - s));
 }
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 resolution of every consumer): one v_rcp and one
