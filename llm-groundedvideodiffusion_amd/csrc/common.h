@@ -57,6 +57,20 @@ LVD_DEV float gelu_erf_grad_f(float x) {
   float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// gelu(x) and gelu'(x) together: the exponential inside the erf approximation IS exp(-x^2/2), the density's — one v_exp, one v_rcp and
+// one polynomial for both (the GEGLU backward needs both per element)
+LVD_DEV void gelu_erf_both(float x, float& val, float& grad) {
+  const float a = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = fast_exp2(-1.4426950408889634f * a * a);  // exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.f + copysignf(fmaf(-pl * t, e, 1.f), x));
+  val = x * cdf;
+  grad = fmaf(x * 0.3989422804014327f, e, cdf);
+}
 
 LVD_DEV float wave_sum(float v) {
 #pragma unroll

@@ -98,8 +98,10 @@ __global__ void geglu_bwd_kernel(const lvd_bf16* pre, int ldp, const lvd_bf16* d
     float dh[4], dg[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      dh[e] = dv[e] * gelu_erf_f(gv[e]);
-      dg[e] = dv[e] * hv[e] * gelu_erf_grad_f(gv[e]);
+      float ge, gg;
+      gelu_erf_both(gv[e], ge, gg);
+      dh[e] = dv[e] * ge;
+      dg[e] = dv[e] * hv[e] * gg;
     }
     lvd_bf16* dp = dpre + row * lddp + blk * 64 + w;
     uint2 o1, o2;
