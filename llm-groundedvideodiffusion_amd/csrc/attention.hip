@@ -265,6 +265,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_v2_kernel(const lvd_attn_para
   const int nt = (skv + 63) >> 6;
   load_tile(0);
   store_tile(0);
+  // Every global load issued so far (the Q fragments above all) is retired HERE: otherwise the compiler, which merges the loop's
+  // entry state with its back edge, keeps a vmcnt wait for the Q registers in front of the first MFMAs of every iteration — and
+  // that wait also drains the K/V prefetch issued a few instructions earlier, exposing its whole latency once per tile.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   for (int kt = 0; kt < nt; ++kt) {
     const int buf = kt & 1;

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_v2_kernel(const lvd_attn_b
   const int nt = (skv + 63) >> 6;
   load_tile(0);
   store_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no pre-loop load may stay "pending" into the loop (see attention.hip, v2 forward)
   __syncthreads();
   for (int kt = 0; kt < nt; ++kt) {
     const int b = kt & 1;
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_v2_kernel(const lvd_attn_
   const int nt = (sq + 63) >> 6;
   load_tile(0);
   store_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no pre-loop load may stay "pending" into the loop (see attention.hip, v2 forward)
   __syncthreads();
   for (int qt = 0; qt < nt; ++qt) {
     const int b = qt & 1;
