@@ -277,16 +277,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_v2_kernel(const lvd_attn_para
     const uint32_t* vt = vt_lds[buf];
     f32x16 st[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
-      const int row = kb * 32 + l31;
+    // the two key blocks alternate: consecutive MFMAs never accumulate into the same registers (a dependent 32x32x16 waits for the
+    // whole pass of its predecessor)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + l31;
         bf16x8 kf = as_bf16x8(kl[row * 8 + ((ks * 2 + hi) ^ ((row >> 1) & 7))]);
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
-    }
     // softmax on the raw scores: the scale is folded into the exponent FMA (max over raw scores, scale > 0)
     float pv[2][16];
     float tmax = -1e30f;
