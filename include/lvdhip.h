@@ -213,6 +213,8 @@ int lvdhip_layernorm_bwd(const lvd_ln_bwd_params* p, void* stream);
  *                        into the loads/stores),
  *   text cross-attn     (K/V rows = 77 text tokens of the batch item),
  *   GLIGEN gated self-attn (second K/V segment = 30 grounding tokens, models/attention.py:44-57).
+ * Every operand and result is moved as whole 16-byte pieces of a head's 128-byte row: all pointers 16-byte aligned, every leading
+ * dimension (ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv) a multiple of 8 elements.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const lvd_bf16* q; int32_t ldq;       /* head h at column h*64 */
