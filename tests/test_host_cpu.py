@@ -201,3 +201,46 @@ def test_gemm_workspace_query_needs_no_gpu():
     p.M = 0
     assert hip.lib().lvdhip_gemm_workspace_bytes(ctypes.byref(p), ctypes.byref(n)) != 0
     assert b"gemm_workspace_bytes" in hip.lib().lvdhip_last_error()
+
+
+def test_gemm_autotune_table_round_trip(tmp_path):
+    """The per-shape variant choices survive save -> load (tuple keys incl. the conv (stride, upsample) pair): what
+    generate.py --gemm_autotune_table relies on to make every rank run the same kernels."""
+    from lvd_amd import ops
+    saved = dict(ops._gemm_choice)
+    try:
+        ops._gemm_choice.clear()
+        ops._gemm_choice[(0, 138240, 960, 320, 0, 320, 320, None, 0, False, False)] = 117
+        ops._gemm_choice[(1, 138240, 320, 2880, 0, 320, 320, (1, 0), 0, True, False)] = 47
+        ops._gemm_choice[(2, 4320, 1280, 3840, 0, 1280, 1280, None, 0, True, True)] = 45
+        want = dict(ops._gemm_choice)
+        path = tmp_path / "table.json"
+        ops.save_gemm_autotune_table(str(path))
+        ops._gemm_choice.clear()
+        ops.load_gemm_autotune_table(str(path))
+        assert ops.gemm_autotune_table() == want
+    finally:
+        ops._gemm_choice.clear()
+        ops._gemm_choice.update(saved)
+
+
+def test_groupnorm_chunking_rules():
+    """Statistics chunks: enough workgroups for 256 CUs, never fewer than the minimum rows per chunk, never zero."""
+    from lvd_amd import ops
+    assert ops._gn_chunks(48, 2880) == 42            # level 0, 2-D norm: 2048 // 48
+    assert ops._gn_chunks(2, 69120) == 1024          # level 0, 5-D norm
+    assert ops._gn_chunks(2, 1080) == 16             # 5x9 level, forward: 64-row chunks
+    assert ops._gn_chunks(2, 1080, 32) == 33         # ... backward statistics: 32-row chunks
+    assert ops._gn_chunks(4096, 10) == 1 and ops._gn_chunks(1, 1) == 1
+
+
+def test_test_tokenizer_ids_do_not_depend_on_call_order():
+    """The stand-in tokenizer of the test suite assigns ids from the token text alone, so two processes that see different subsets
+    of a prompt list (sharded generate.py) embed the same prompt identically."""
+    from oracle.fake_tokenizer import FakeClipTokenizer
+    a, b = FakeClipTokenizer(), FakeClipTokenizer()
+    a(["a dog runs on the beach"], return_tensors="np")
+    ids_a = a(["a red car turns left"], return_tensors="np")["input_ids"]
+    ids_b = b(["a red car turns left"], return_tensors="np")["input_ids"]
+    assert (ids_a == ids_b).all()
+    assert a._convert_id_to_token(ids_a[0][2]) == "red</w>"
