@@ -30,7 +30,7 @@ constexpr int VT_PITCH = 18;  // dwords per d-row of the transposed V tile (16 k
 
 __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p) {
   __shared__ uint32_t vt[64 * VT_PITCH];
-  __shared__ uint4 qk[32 * 8];  // Q tile, then one K tile at a time: [row][16-byte chunk ^ (row & 7)]
+  __shared__ uint4 qk[32 * 8];  // Q tile, then one K tile at a time: [row][16-byte chunk ^ ((row >> 1) & 7)]
 
   const int lane = threadIdx.x;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -50,14 +50,14 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
   // (eight lanes per row) instead of 32 bytes of 32 different rows per instruction — four instructions re-touching the same lines,
   // which at 16 waves per CU do not survive in the L1.  XOR chunk swizzle: conflict-free ds_read_b128 in the fragment layout.
   const int sr = lane >> 3, scn = lane & 7;  // staging role: row sr (+8 per instruction), 16-byte chunk scn
-  auto frag = [&](int ks) { return as_bf16x8(qk[l31 * 8 + ((ks * 2 + hi) ^ (l31 & 7))]); };
+  auto frag = [&](int ks) { return as_bf16x8(qk[l31 * 8 + ((ks * 2 + hi) ^ ((l31 >> 1) & 7))]); };
   bf16x8 qf[4];
   {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = it * 8 + sr;
       const long row = qbase + (long)min(qt * 32 + r, p.sq - 1) * p.q_step;
-      qk[r * 8 + (scn ^ (r & 7))] = ldg16(p.q + row * p.ldq + h * 64 + scn * 8);
+      qk[r * 8 + (scn ^ ((r >> 1) & 7))] = ldg16(p.q + row * p.ldq + h * 64 + scn * 8);
     }
     __syncthreads();
 #pragma unroll
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = it * 8 + sr;
-        qk[r * 8 + (scn ^ (r & 7))] = kr[it];
+        qk[r * 8 + (scn ^ ((r >> 1) & 7))] = kr[it];
       }
     }
     // ---- V tile -> LDS, transposed: vt[d][key pair]
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
   // O tile back through the LDS tile (the loop's last barrier retired every read of it): whole 128-byte head rows per store
   // instruction instead of 16 bytes of 32 different rows
   {
-    uint2* ot = reinterpret_cast<uint2*>(qk);  // [query][16-byte chunk ^ (query & 7)], two uint2 per chunk
+    uint2* ot = reinterpret_cast<uint2*>(qk);  // [query][16-byte chunk ^ ((query >> 1) & 7)], two uint2 per chunk
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       uint2 w0, w1;
@@ -188,14 +188,14 @@ __global__ __launch_bounds__(64, 4) void attn_fwd_kernel(const lvd_attn_params p
       w0.y = pack2bf(o0[rq * 4 + 2] * inv, o0[rq * 4 + 3] * inv);
       w1.x = pack2bf(o1[rq * 4 + 0] * inv, o1[rq * 4 + 1] * inv);
       w1.y = pack2bf(o1[rq * 4 + 2] * inv, o1[rq * 4 + 3] * inv);
-      ot[(l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi] = w0;        // d = 8 rq + 4 hi .. +3
-      ot[(l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi] = w1;  // d = 32 + 8 rq + 4 hi .. +3
+      ot[(l31 * 8 + (rq ^ ((l31 >> 1) & 7))) * 2 + hi] = w0;        // d = 8 rq + 4 hi .. +3
+      ot[(l31 * 8 + ((rq + 4) ^ ((l31 >> 1) & 7))) * 2 + hi] = w1;  // d = 32 + 8 rq + 4 hi .. +3
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = it * 8 + sr, q = qt * 32 + r;
-      if (q < p.sq) stg16(p.o + (qbase + (long)q * p.q_step) * p.ldo + h * 64 + scn * 8, qk[r * 8 + (scn ^ (r & 7))]);
+      if (q < p.sq) stg16(p.o + (qbase + (long)q * p.q_step) * p.ldo + h * 64 + scn * 8, qk[r * 8 + (scn ^ ((r >> 1) & 7))]);
     }
   }
   if (qi < p.sq && p.lse && hi == 0) p.lse[((long)s * p.heads + h) * p.sq + qi] = (m + log2f(ltot)) * 0.6931471805599453f;

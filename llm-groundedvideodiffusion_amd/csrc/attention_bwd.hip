@@ -57,15 +57,15 @@ LVD_DEV float dot8(uint4 a, uint4 b) {
          bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
 
-// Row-major 32-row x 128-byte LDS tile with an XOR chunk swizzle ([row][16-byte chunk ^ (row & 7)]): global loads and stores cover
+// Row-major 32-row x 128-byte LDS tile with an XOR chunk swizzle ([row][16-byte chunk ^ ((row >> 1) & 7)]): global loads and stores cover
 // whole head rows (eight lanes per row) and the MFMA fragments are conflict-free ds_read_b128.  sr = lane >> 3 (row within an
 // 8-row instruction), scn = lane & 7 (chunk).
-LVD_DEV bf16x8 tile_frag(const uint4* tile, int l31, int hi, int ks) { return as_bf16x8(tile[l31 * 8 + ((ks * 2 + hi) ^ (l31 & 7))]); }
+LVD_DEV bf16x8 tile_frag(const uint4* tile, int l31, int hi, int ks) { return as_bf16x8(tile[l31 * 8 + ((ks * 2 + hi) ^ ((l31 >> 1) & 7))]); }
 LVD_DEV void tile_put(uint4* tile, const uint4 v[4], int sr, int scn) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int r = it * 8 + sr;
-    tile[r * 8 + (scn ^ (r & 7))] = v[it];
+    tile[r * 8 + (scn ^ ((r >> 1) & 7))] = v[it];
   }
 }
 // transposed [64 d][32 rows] staging of a tile that already sits row-major in LDS (instead of a second trip to global memory)
@@ -74,8 +74,8 @@ LVD_DEV void stage_transposed_from_tile(uint32_t* lds, const uint4* tile, int vj
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int c = vdc + 4 * half, d0 = c * 8;
-    const uint4 a = tile[r0 * 8 + (c ^ (r0 & 7))];
-    const uint4 b = tile[r1 * 8 + (c ^ (r1 & 7))];
+    const uint4 a = tile[r0 * 8 + (c ^ ((r0 >> 1) & 7))];
+    const uint4 b = tile[r1 * 8 + (c ^ ((r1 >> 1) & 7))];
     const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -187,14 +187,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const lvd_attn_bwd_para
       w0.y = pack2bf(dq0[rq * 4 + 2] * f, dq0[rq * 4 + 3] * f);
       w1.x = pack2bf(dq1[rq * 4 + 0] * f, dq1[rq * 4 + 1] * f);
       w1.y = pack2bf(dq1[rq * 4 + 2] * f, dq1[rq * 4 + 3] * f);
-      ot[(l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi] = w0;
-      ot[(l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi] = w1;
+      ot[(l31 * 8 + (rq ^ ((l31 >> 1) & 7))) * 2 + hi] = w0;
+      ot[(l31 * 8 + ((rq + 4) ^ ((l31 >> 1) & 7))) * 2 + hi] = w1;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = it * 8 + sr, q = qt * 32 + r;
-      if (q < p.sq) stg16(bp.dq + (qbase + (long)q * p.q_step) * bp.lddq + h * 64 + scn * 8, ta[r * 8 + (scn ^ (r & 7))]);
+      if (q < p.sq) stg16(bp.dq + (qbase + (long)q * p.q_step) * bp.lddq + h * 64 + scn * 8, ta[r * 8 + (scn ^ ((r >> 1) & 7))]);
     }
   }
 }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_par
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       uint2 w;
-      const int c0 = (l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi, c1 = (l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi;
+      const int c0 = (l31 * 8 + (rq ^ ((l31 >> 1) & 7))) * 2 + hi, c1 = (l31 * 8 + ((rq + 4) ^ ((l31 >> 1) & 7))) * 2 + hi;
       w.x = pack2bf(dk0[rq * 4 + 0] * f, dk0[rq * 4 + 1] * f); w.y = pack2bf(dk0[rq * 4 + 2] * f, dk0[rq * 4 + 3] * f);
       ok[c0] = w;
       w.x = pack2bf(dk1[rq * 4 + 0] * f, dk1[rq * 4 + 1] * f); w.y = pack2bf(dk1[rq * 4 + 2] * f, dk1[rq * 4 + 3] * f);
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const lvd_attn_bwd_par
       const int r = it * 8 + sr, k = ktile * 32 + r;
       if (k < p.skv) {
         const long krow = kvbase + (long)k * p.kv_step;
-        stg16(bp.dk + krow * bp.lddk + h * 64 + scn * 8, ta[r * 8 + (scn ^ (r & 7))]);
-        stg16(bp.dv + krow * bp.lddv + h * 64 + scn * 8, tb[r * 8 + (scn ^ (r & 7))]);
+        stg16(bp.dk + krow * bp.lddk + h * 64 + scn * 8, ta[r * 8 + (scn ^ ((r >> 1) & 7))]);
+        stg16(bp.dv + krow * bp.lddv + h * 64 + scn * 8, tb[r * 8 + (scn ^ ((r >> 1) & 7))]);
       }
     }
   }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const lvd_attn_bwd_p
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       uint2 w;
-      const int c0 = (l31 * 8 + (rq ^ (l31 & 7))) * 2 + hi, c1 = (l31 * 8 + ((rq + 4) ^ (l31 & 7))) * 2 + hi;
+      const int c0 = (l31 * 8 + (rq ^ ((l31 >> 1) & 7))) * 2 + hi, c1 = (l31 * 8 + ((rq + 4) ^ ((l31 >> 1) & 7))) * 2 + hi;
       w.x = pack2bf(dq0[rq * 4 + 0] * f, dq0[rq * 4 + 1] * f); w.y = pack2bf(dq0[rq * 4 + 2] * f, dq0[rq * 4 + 3] * f);
       oq[c0] = w;
       w.x = pack2bf(dq1[rq * 4 + 0] * f, dq1[rq * 4 + 1] * f); w.y = pack2bf(dq1[rq * 4 + 2] * f, dq1[rq * 4 + 3] * f);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const lvd_attn_bwd_p
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int r = it * 8 + sr, c = r * 8 + (scn ^ (r & 7));
+      const int r = it * 8 + sr, c = r * 8 + (scn ^ ((r >> 1) & 7));
       if (r < p.sq) stg16(bp.dq + (qbase + (long)r * p.q_step) * bp.lddq + h * 64 + scn * 8, tq[c]);
       if (r < p.skv) {
         const long krow = kvbase + (long)r * p.kv_step;
