@@ -62,17 +62,22 @@ enum {
   LVD_GEMM_V_SPLITK_WIDE = 25, /* K split on the 8-wave 256x320 / 256x256 geometries (small-M, long-K deep-level layers) */
   LVD_GEMM_V_RING256W_TAIL = 31,   /* RING256W on the rows that fill whole rounds of the 256 CUs, split-K on the remainder */
   LVD_GEMM_V_RING128x320_TAIL = 37, /* RING128x320 on whole rounds of 512 workgroup slots, split-K on the remainder */
-  /* 3x3 stride-1 convolutions and temporal (3,1,1) convolutions with the im2col tile resident in LDS (conv_halo.hip): per
-     32-channel chunk the rows a 512 x 160|128 tile needs for all its taps are staged once (3x3: the tile's rows + one image row
-     + one pixel of halo; temporal: 512/F pixels x all F frames) and the taps are shifted LDS views; 8 waves, 1 workgroup/CU.
-     Products the kernel cannot take (stride 2, fused upsample, two sources, W > 87, Cin % 32) run the RING256W equivalents. */
+  /* 3x3 stride-1 convolutions (optionally with the nearest-x2 upsample fused, even H/W) and temporal (3,1,1) convolutions with the
+     im2col tile resident in LDS (conv_halo.hip): per 32-channel chunk the rows a 512 x 160|128 tile needs for all its taps are
+     staged once (3x3: the tile's rows + one image row + one pixel of halo; temporal: 512/F pixels x all F frames) and the taps are
+     shifted LDS views; 8 waves, 1 workgroup/CU.  Products the kernel cannot take (stride 2, two sources, W > 87, Cin % 32) run
+     the RING256W equivalents. */
+  LVD_GEMM_V_CONV_HALO = 41,
+  LVD_GEMM_V_CONV_HALO_SPLITK = 45, /* channel chunks split over workgroups + deterministic slab reduction */
+  LVD_GEMM_V_CONV_HALO_TAIL = 47,   /* CONV_HALO on whole rounds of the 256 CUs, CONV_HALO_SPLITK on the remaining tiles */
   /* + LVD_GEMM_V_ADMA on a RING128 / RING256N / RING256W / RING128x320 / SPLITK / SPLITK_WIDE / *_TAIL variant: the same
      geometry with its LDS-DMA issued from buffer descriptors in inline assembly, counted waits that really leave tiles in
      flight, bias row staged by the DMA engine (plain loader, K % 32 == 0; anything else runs the base variant) */
   LVD_GEMM_V_ADMA = 100,
-  LVD_GEMM_V_CONV_HALO = 41,
-  LVD_GEMM_V_CONV_HALO_SPLITK = 45, /* channel chunks split over workgroups + deterministic slab reduction */
-  LVD_GEMM_V_CONV_HALO_TAIL = 47    /* CONV_HALO on whole rounds of the 256 CUs, CONV_HALO_SPLITK on the remaining tiles */
+  /* + LVD_GEMM_V_ADMA64 on RING256W / SPLITK_WIDE / RING256W_TAIL: 64-deep K tiles in a two-slot ring — every DMA instruction
+     moves 8 rows x one full 128-byte line (plain loader, K % 64 == 0, K >= 128; anything else runs the + LVD_GEMM_V_ADMA form).
+     A code that names no geometry (e.g. 141, 210) is an error, not a fallback. */
+  LVD_GEMM_V_ADMA64 = 200
 };
 
 typedef struct {

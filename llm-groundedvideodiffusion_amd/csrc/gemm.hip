@@ -331,12 +331,20 @@ bool wide320_fills_better(const lvd_gemm_params* p) {
 
 int run_with_tail(const lvd_gemm_params* p, void* stream, int v);
 
-// One launch (two for split-K) of a pinned or heuristic tile geometry over rows [m_begin, M).
+// One launch (two for split-K) of a pinned or heuristic tile geometry over rows [m_begin, M).  Returns 3 for a variant code
+// that names no geometry (a damaged autotune table must not silently pin some kernel).
 int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   dim3 grid(tiles);
   hipStream_t s = (hipStream_t)stream;
+  // + LVD_GEMM_V_ADMA / + LVD_GEMM_V_ADMA64: the asm buffer-DMA instantiations of a ring geometry (gemm_ring.hip); stripped first,
+  // so that every base code below is looked at once
+  int adma = 0;
+  if (v >= 300) return 3;
+  if (v >= LVD_GEMM_V_ADMA64) { adma = 200; v -= LVD_GEMM_V_ADMA64; }
+  else if (v >= LVD_GEMM_V_ADMA) { adma = 100; v -= LVD_GEMM_V_ADMA; }
   if (v == 0) {
+    if (adma) return 3;
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_variants.txt):
     //   under-filled grids            -> 128x128x64 register-staged (fewest, longest tiles)
     //   conv / tconv / long-K linear  -> LDS-DMA ring, 3 stages, 3 workgroups per CU
@@ -349,23 +357,25 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
   // LDS-resident im2col (conv_halo.hip); products it cannot take fall through to the matching implicit-im2col geometry
   if (v == LVD_GEMM_V_CONV_HALO || v == LVD_GEMM_V_CONV_HALO_SPLITK || v == LVD_GEMM_V_CONV_HALO_TAIL) {
+    if (adma) return 3;
     if (lvd_conv_halo_eligible(p))
       return lvd_conv_halo_dispatch(p, stream, v == LVD_GEMM_V_CONV_HALO ? 0 : (v == LVD_GEMM_V_CONV_HALO_SPLITK ? 1 : 2));
     if (v == LVD_GEMM_V_CONV_HALO_TAIL) return run_with_tail(p, stream, LVD_GEMM_V_RING256W_TAIL);
     v = v == LVD_GEMM_V_CONV_HALO ? LVD_GEMM_V_RING256W : LVD_GEMM_V_SPLITK_WIDE;
   }
-  const int adma = v >= LVD_GEMM_V_ADMA ? 100 : 0;  // asm buffer-DMA instantiation of the same ring geometry (gemm_ring.hip)
-  if (adma) v -= LVD_GEMM_V_ADMA;
-  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5 + (v <= 6 ? adma : 0));
-  if (v == 14) return lvd_gemm_ring_dispatch(p, stream, 8);
-  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20 + adma);
+  const int a100 = adma ? 100 : 0;  // geometries without a 64-deep form take the 32-deep asm-DMA one
+  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5 + (v <= 6 ? a100 : 0));
+  if (v == 14 && !adma) return lvd_gemm_ring_dispatch(p, stream, 8);
+  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20 + a100);
   if (v == LVD_GEMM_V_SPLITK_WIDE) return lvd_gemm_ring_dispatch(p, stream, (n320 && wide320_fills_better(p) ? 24 : 25) + adma);
-  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 12 : 0) + adma);
+  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 12 : 0) + a100);
   if (v == 11) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 4 : 5) + adma);
-  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, ((p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3) + adma);
+  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, ((p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3) + a100);
+  if (adma) return 3;
   if (v == 1) return launch_gemm<32, 3>(p, grid, s);
   if (v == 2) return launch_gemm<32, 4>(p, grid, s);
-  return launch_gemm<64, 2>(p, grid, s);
+  if (v == 10) return launch_gemm<64, 2>(p, grid, s);
+  return 3;
 }
 
 // Tail-aware launch.  All tiles of one GEMM cost the same, so a grid of T tiles on S resident workgroup slots runs
@@ -382,7 +392,7 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
     if (cus <= 0) cus = 256;
   }
   const bool n320 = p->act != LVD_ACT_GEGLU && p->N % 320 == 0;
-  const int adma = v >= LVD_GEMM_V_ADMA ? LVD_GEMM_V_ADMA : 0;
+  const int adma = v >= LVD_GEMM_V_ADMA64 ? LVD_GEMM_V_ADMA64 : (v >= LVD_GEMM_V_ADMA ? LVD_GEMM_V_ADMA : 0);
   v -= adma;
   const bool wide = v == LVD_GEMM_V_RING256W_TAIL;
   const int base = (wide ? LVD_GEMM_V_RING256W : LVD_GEMM_V_RING128x320) + adma;
@@ -400,7 +410,7 @@ int run_with_tail(const lvd_gemm_params* p, void* stream, int v) {
   tail.m_begin = head.M;
   int rc = run_variant(&head, stream, base);
   if (rc) return rc;
-  return run_variant(&tail, stream, ((p->ws && p->act == LVD_ACT_NONE) ? LVD_GEMM_V_SPLITK : LVD_GEMM_V_RING128) + adma);
+  return run_variant(&tail, stream, ((p->ws && p->act == LVD_ACT_NONE) ? LVD_GEMM_V_SPLITK : LVD_GEMM_V_RING128) + (adma ? LVD_GEMM_V_ADMA : 0));
 }
 
 }  // namespace
@@ -425,9 +435,10 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   }();
   int v = p->variant ? p->variant : variant;
   int rc;
-  const int vb = v >= LVD_GEMM_V_ADMA ? v - LVD_GEMM_V_ADMA : v;
+  const int vb = v % 100;  // + LVD_GEMM_V_ADMA / ADMA64 select the main-loop generation of the same geometry
   if (vb == LVD_GEMM_V_RING256W_TAIL || vb == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
   else rc = run_variant(p, stream, v);
+  LVD_CHECK(rc != 3, "gemm: variant %d names no tile geometry", v);
   LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();
   return 0;

@@ -28,6 +28,31 @@
 
 namespace {
 
+// Developer ablations of the ping-pong main loops (tools/build_ablations.sh builds side libraries with -DLVD_ABL=1|2; never defined in
+// the shipped library): 1 = MFMAs compiled out (fragments kept live), 2 = in-loop DMA compiled out (the prologue tiles are re-read).
+#ifndef LVD_ABL
+#define LVD_ABL 0
+#endif
+template <class T>
+LVD_DEV void keep_live(const T& v) { asm volatile("" ::"v"(v)); }
+// -DLVD_TRACE (tools/build_ablations.sh, never in the shipped library): waves 0 and 4 of one workgroup stamp s_memtime at the phase
+// edges of a few K tiles into a spare LDS strip and dump it to p.ws at the end (tools/phase_trace.py reads it back).
+#ifdef LVD_TRACE
+#define LVD_TRQ 128
+#define LVD_STAMP()                                                         \
+  do {                                                                      \
+    if (tr_on && tr_n < 126) {                                              \
+      const unsigned long tt_ = __builtin_amdgcn_s_memtime();               \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+      if (lane == 0) tr_buf[tr_n] = (unsigned)tt_;                          \
+      ++tr_n;                                                               \
+    }                                                                       \
+  } while (0)
+#else
+#define LVD_TRQ 0
+#define LVD_STAMP() do {} while (0)
+#endif
+
 // WM x WN waves (4 or 8); wave tile (FM*32) x (FN*32); STAGES-deep LDS ring
 // ADMA (plain loader, K % RBK == 0): the LDS-DMA is issued as inline assembly from raw buffer descriptors (gemm_tile.h dma16),
 // so the compiler neither sees a pending LDS write (no vmcnt(0) in front of every phase's first ds_read: the counted waits
@@ -35,7 +60,9 @@ namespace {
 // products are never stored), K tiles past the end re-read the last one.
 template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false, bool ADMA = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
-  static_assert(!ADMA || (MODE == LVD_A_PLAIN && RBK == 32), "asm DMA: plain loader, 32-wide K tiles");
+  static_assert(!ADMA || (MODE == LVD_A_PLAIN && (RBK == 32 || RBK == 64)), "asm DMA: plain loader, 32- or 64-wide K tiles");
+  constexpr bool PP64 = PP && RBK == 64;                 // two-slot ring of 128-byte rows, consumed in two 32-deep halves (below)
+  static_assert(!PP64 || (ADMA && STAGES == 2), "PP64: asm DMA, two slots");
   constexpr int NW = WM * WN;
   constexpr int RCH = RBK / 8;                            // 16-byte chunks per tile row (4: 64 B rows, 8: full 128 B lines)
   constexpr int RPI = 64 / RCH;                          // tile rows covered by one wave-wide glds instruction
@@ -47,13 +74,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   static_assert(AINS % NW == 0, "BM must be a multiple of RPI * waves");
   constexpr int LPS = APW + BPW;                         // glds per wave per stage (uniform -> one vmcnt immediate)
   constexpr int BIASQ = ADMA ? (BN * 4 + 1023) / 1024 * 64 : 0;               // ADMA: the tile's bias row is staged in LDS by the DMA engine too
-  __shared__ uint4 lds[STAGES * TILE + BIASQ];
+  __shared__ uint4 lds[STAGES * TILE + BIASQ + (PP ? LVD_TRQ : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, hi = lane >> 5;
+#ifdef LVD_TRACE
+  unsigned* tr_buf = reinterpret_cast<unsigned*>(lds + STAGES * TILE + BIASQ) + (wave >> 2) * 128;
+  int tr_n = 0;
+  const bool tr_blk = PP && (int)blockIdx.x == (int)(gridDim.x / 2) && (wave & 3) == 0;
+  bool tr_on = false;
+  const unsigned long tr_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
   const int nb = gridDim.x;
   int id;
@@ -193,7 +227,110 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     }
   };
 
-  if constexpr (PP) {
+  if constexpr (PP64) {
+    // 64-deep K tiles, two LDS slots (RBK = 64).  Every DMA instruction moves 8 rows x one full 128-byte line instead of 16 rows
+    // x half a line: half the lines per staged byte through the address unit and the L1, and no line is fetched twice by
+    // consecutive K tiles.  The registers hold the fragments of 32 of the 64 columns, so a tile is consumed as two halves, each a
+    // ping-pong phase pair as in the 32-deep schedule further down (waves 4-7 = group 1 one phase behind waves 0-3 = group 0):
+    //   phase:      4j        4j+1      4j+2      4j+3
+    //   group 0:  L(j,h0)   M(j,h0)   L(j,h1)   M(j,h1)
+    //   group 1:  M(j-1,h1) L(j,h0)   M(j,h0)   L(j,h1)
+    // A slot is free once group 1 has read its second half (end of phase 4j+3) and has to hold tile j+2 at phase 4j+8.  A wave's
+    // share of a tile (LPS instructions) goes out in two batches, one per L phase:
+    //   group 0: batch 0 of tile j+1 in L(j,h0), batch 1 in L(j,h1)     -> waits vmcnt(0) behind the MFMAs of M(j,h1)
+    //   group 1: batch 1 of tile j+1 in L(j,h0); batch 0 of tile j+2 at the END of L(j,h1), behind its own last reads of that
+    //            slot (lgkmcnt(0) first)                                  -> waits vmcnt(NB0) there: everything but that batch
+    // RAW: all of tile j+1 is waited for by the end of phase 4j+3, one barrier before its first reader.  WAR: every batch is
+    // issued at least one barrier after the last read of the slot it overwrites (group 1's own reads: after their lgkmcnt(0)).
+    constexpr int NB0 = (LPS + 1) / 2;
+    const int group = wave >> 2;
+    auto batch0 = [&](int kt, int slot) {
+      if (LVD_ABL == 2 && kt > 1) return;
+#pragma unroll
+      for (int idx = 0; idx < NB0; ++idx) stage_one(kt, slot, idx);
+    };
+    auto batch1 = [&](int kt, int slot) {
+      if (LVD_ABL == 2 && kt > 1) return;
+#pragma unroll
+      for (int idx = NB0; idx < LPS; ++idx) stage_one(kt, slot, idx);
+    };
+    if (group == 1 && nk > 1) {
+      batch0(1, 1);
+      wait_vmcnt<NB0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if constexpr (LDS_BIAS) acc_from_lds_bias();
+    if (group == 1) __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < nk; ++j) {
+      const int slot = j & 1;
+      const uint4* A = lds + slot * TILE;
+      const uint4* B = A + BM * RCH;
+#ifdef LVD_TRACE
+      tr_on = tr_blk && j >= 4 && j < 8;
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        LVD_STAMP();
+        bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int c = (h * 2 + ks) * 2 + hi;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            int row = (wm * FM + i) * 32 + l31;
+            af[ks][i] = as_bf16x8(A[row * RCH + swz(row, c)]);
+          }
+#pragma unroll
+          for (int jn = 0; jn < FN; ++jn) {
+            int row = (wn * FN + jn) * 32 + l31;
+            bfr[ks][jn] = as_bf16x8(B[row * RCH + swz(row, c)]);
+          }
+        }
+        if (h == 0) {
+          if (j + 1 < nk) {
+            if (group == 0) batch0(j + 1, slot ^ 1);
+            else batch1(j + 1, slot ^ 1);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (group == 0) {
+          if (j + 1 < nk) batch1(j + 1, slot ^ 1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (j + 2 < nk) {
+            batch0(j + 2, slot);
+            wait_vmcnt<NB0>();
+          } else {
+            wait_vmcnt<0>();
+          }
+        }
+        LVD_STAMP();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        LVD_STAMP();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+              if (LVD_ABL == 1) { keep_live(bfr[ks][jn]); keep_live(af[ks][i]); continue; }
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][jn], af[ks][i], acc[i][jn], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        if (h == 1 && group == 0) wait_vmcnt<0>();
+        LVD_STAMP();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PP) {
     // Ping-pong schedule for the 8-wave geometries (two waves per SIMD).  In the lock-step loop below both waves of a
     // SIMD read their fragments at the same time and then compete for the MFMA pipe at the same time.  Here the K tile
     // is two phases — L: fragments LDS -> registers, refill DMA, waits;  M: nothing but MFMAs — and waves 4-7 run one
@@ -212,6 +349,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
       const int nslot = slot == 0 ? STAGES - 1 : slot - 1;
       const uint4* A = lds + slot * TILE;
       const uint4* B = A + BM * RCH;
+#ifdef LVD_TRACE
+      tr_on = tr_blk && kt >= 8 && kt < 16;
+#endif
+      LVD_STAMP();
       bf16x8 af[RBK / 16][FM], bfr[RBK / 16][FN];
 #pragma unroll
       for (int ks = 0; ks < RBK / 16; ++ks) {
@@ -227,21 +368,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
           bfr[ks][j] = as_bf16x8(B[row * RCH + swz(row, c)]);
         }
       }
-      stage(kt + STAGES - 1, nslot);
+      if (!(LVD_ABL == 2 && kt > 0)) stage(kt + STAGES - 1, nslot);
       wait_vmcnt<(STAGES - 2) * LPS>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      LVD_STAMP();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      LVD_STAMP();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < RBK / 16; ++ks)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
+          for (int j = 0; j < FN; ++j) {
+            if (LVD_ABL == 1) { keep_live(bfr[ks][j]); keep_live(af[ks][i]); continue; }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+          }
       __builtin_amdgcn_s_setprio(0);
+      LVD_STAMP();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -297,6 +443,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     }
   }
   wait_vmcnt<0>();
+#ifdef LVD_TRACE
+  if constexpr (PP) {
+    if (tr_blk && p.ws) {
+      const unsigned long tr_t1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      unsigned* dst = reinterpret_cast<unsigned*>(p.ws) + (wave >> 2) * 128;
+      if (lane == 0) { tr_buf[126] = (unsigned)(tr_t1 - tr_t0); tr_buf[127] = tr_n; }
+      __builtin_amdgcn_wave_barrier();
+      dst[lane] = tr_buf[lane];
+      dst[lane + 64] = tr_buf[lane + 64];
+    }
+  }
+#endif
 
   const int mbase = p.m_begin + tm * BM + wm * FM * 32;
   const int nbase = tn * BN + wn * FN * 32;
@@ -355,7 +514,7 @@ namespace {
 // K split over workgroups: SLOTS = workgroups resident on the device for this geometry (one full round, never a second
 // partial one).  The wide ping-pong geometries stage 2.2x fewer bytes per flop than 128x128 and are what the small-M
 // deep-level layers (M = 1080 ... 8640, K up to 23040) need once the K split gives them enough workgroups.
-template <int WM, int WN, int FM, int FN, int STAGES, bool PP, int SLOTS, bool ADMA = false>
+template <int WM, int WN, int FM, int FN, int STAGES, bool PP, int SLOTS, bool ADMA = false, int RBK = 32>
 int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   lvd_gemm_params p = *pp;
@@ -368,11 +527,18 @@ int launch_splitk(const lvd_gemm_params* pp, hipStream_t s) {
   p.ksplit = ks;
   dim3 grid(tiles * ks), block(64 * WM * WN);
   switch (p.mode) {
-    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, 32, true, PP, ADMA>), grid, block, 0, s, p); break;
-    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
-    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
-    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
-    default: return 1;
+    case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, true, PP, ADMA>), grid, block, 0, s, p); break;
+    default:
+      if constexpr (RBK == 32) {
+        switch (p.mode) {
+          case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+          case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+          case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, 32, true, PP>), grid, block, 0, s, p); break;
+          default: return 1;
+        }
+      } else {
+        return 1;
+      }
   }
   lvd_splitk_reduce_launch(&p, s);
   return 0;
@@ -385,10 +551,17 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   dim3 grid(tiles), block(64 * WM * WN);
   switch (p->mode) {
     case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, false, PP, ADMA>), grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
-    case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
-    case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
-    default: return 1;
+    default:
+      if constexpr (!ADMA) {  // the asm-DMA instantiations exist for the plain loader only
+        switch (p->mode) {
+          case LVD_A_CONV3X3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+          case LVD_A_TCONV3: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_TCONV3, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+          case LVD_A_CONV3X3_T2: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_CONV3X3_T2, WM, WN, FM, FN, STAGES, RBK, false, PP>), grid, block, 0, s, *p); break;
+          default: return 1;
+        }
+      } else {
+        return 1;
+      }
   }
   return 0;
 }
@@ -404,6 +577,20 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
   const bool adma_ok = p->mode == LVD_A_PLAIN && p->K % 32 == 0 && p->rowbias == nullptr && p->N >= 4 &&
                        (p->a2 == nullptr || p->c1 % 32 == 0) &&
                        (long)p->M * (p->lda1 > p->lda2 ? p->lda1 : p->lda2) < (1L << 30) && (long)p->N * p->K < (1L << 30);
+  if (geometry >= 200) {  // +200: 64-deep K tiles on the 8-wave geometries (two LDS slots, full-line DMA); anything else -> the +100 form
+    geometry -= 200;
+    const bool ok64 = adma_ok && p->K % 64 == 0 && p->K >= 128 && (p->a2 == nullptr || p->c1 % 64 == 0);
+    if (ok64) {
+      if (geometry == 24 || geometry == 25) {
+        int rc = geometry == 24 ? launch_splitk<4, 2, 2, 5, 2, true, 256, true, 64>(p, s) : launch_splitk<4, 2, 2, 4, 2, true, 256, true, 64>(p, s);
+        if (rc >= 0) return rc;
+        geometry = geometry == 24 ? 4 : 5;
+      }
+      if (geometry == 4) return launch_ring<4, 2, 2, 5, 2, 64, true, true>(p, s);
+      if (geometry == 5) return launch_ring<4, 2, 2, 4, 2, 64, true, true>(p, s);
+    }
+    geometry += 100;
+  }
   if (geometry >= 100) {
     geometry -= 100;
     if (adma_ok) {

@@ -69,10 +69,10 @@ class ConvGeom:
 # (M, N, K, loader): short-K linears favour many small workgroups, long-K convs the LDS-DMA ring, and the
 # 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
-GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117)  # 100 + v: asm-DMA instantiation of ring variant v
+GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117, 211)  # 100 + v: asm-DMA instantiation of ring variant v; 200 + v: 64-deep K tiles
 SPLITK_VARIANT = 20
 SPLITK_WIDE_VARIANT = 25
-TAIL_VARIANTS = (31, 37, 120, 125, 131, 137)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
+TAIL_VARIANTS = (31, 37, 120, 125, 131, 137, 225, 231)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
 HALO_VARIANTS = (41, 45, 47)  # conv_halo.hip: whole grid / channel-chunk split-K / whole rounds + split-K tail
 _splitk_ws = {}
 
@@ -183,8 +183,10 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
         ws = _splitk_workspace(a1.device, need.value)  # one grow-only buffer per device, shared by all launches of the stream
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"]:
-        key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample) if conv is not None else None, int(out_fp32),
-               res is not None, bool(accumulate))
+        # everything a candidate's eligibility or cost depends on: the conv image (the LDS-resident tap GEMM needs W <= 87), the temporal
+        # geometry (its tile is pixels x all frames) and a temb row-bias (the asm-DMA forms do not take one)
+        key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample, conv.hin, conv.win) if conv is not None else None, int(out_fp32),
+               res is not None, bool(accumulate), frames, hw, rowbias is not None)
         variant = _gemm_choice.get(key) or 0
         if variant == 0 and not torch.cuda.is_current_stream_capturing():  # a capture replays what a warm-up run has tuned
             variant = _tune_gemm(p, key, out)

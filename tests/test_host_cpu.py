@@ -210,9 +210,9 @@ def test_gemm_autotune_table_round_trip(tmp_path):
     saved = dict(ops._gemm_choice)
     try:
         ops._gemm_choice.clear()
-        ops._gemm_choice[(0, 138240, 960, 320, 0, 320, 320, None, 0, False, False)] = 117
-        ops._gemm_choice[(1, 138240, 320, 2880, 0, 320, 320, (1, 0), 0, True, False)] = 47
-        ops._gemm_choice[(2, 4320, 1280, 3840, 0, 1280, 1280, None, 0, True, True)] = 45
+        ops._gemm_choice[(0, 138240, 960, 320, 0, 320, 320, None, 0, False, False, 0, 0, False)] = 117
+        ops._gemm_choice[(1, 138240, 320, 2880, 0, 320, 320, (1, 0, 40, 72), 0, True, False, 0, 0, True)] = 47
+        ops._gemm_choice[(2, 4320, 1280, 3840, 0, 1280, 1280, None, 0, True, True, 24, 180, False)] = 45
         want = dict(ops._gemm_choice)
         path = tmp_path / "table.json"
         ops.save_gemm_autotune_table(str(path))

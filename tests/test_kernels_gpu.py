@@ -350,7 +350,7 @@ def test_elementwise():
     assert abs(ops.reduce_sum(v, 0.5).item() - 0.5 * v.double().sum().item()) < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 5, 11, 17, 20, 41, 45, 105, 111, 117, 120, 131])
+@pytest.mark.parametrize("variant", [1, 5, 11, 17, 20, 41, 45, 105, 111, 117, 120, 131, 211, 231])
 def test_gemm_row_range(variant):
     """m_begin: only rows [m_begin, M) are produced, with absolute row indices (temb row-bias, conv geometry)."""
     M, N, K, rps, mb = 1000, 320, 1032, 250, 389
@@ -370,7 +370,7 @@ def test_gemm_row_range(variant):
     assert (outc[:500] == 0).all()
 
 
-@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37, 41, 47, 105, 109, 111, 117, 131, 137])
+@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37, 41, 47, 105, 109, 111, 117, 131, 137, 211, 231])
 def test_gemm_many_tiles(variant):
     """Grids of several rounds of tiles (tail-aware variants split them into whole rounds + a K-split remainder): short and
     ragged K, ragged M, full epilogue, GEGLU, conv loader."""
@@ -394,7 +394,7 @@ def test_gemm_many_tiles(variant):
     close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{variant} many-tiles conv")
 
 
-@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47, 105, 106, 109, 111, 117, 120, 125, 131, 137])
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
     epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
@@ -434,6 +434,27 @@ def test_gemm_every_tile_geometry(variant):
     reft = F.conv3d(x5, wtc[..., None, None], None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(Bt * Fr * hw, c)
     out = ops.gemm(xt, bf(wtc.permute(0, 2, 1).reshape(c, 3 * c).contiguous()), mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=variant)
     close(out, reft, 6e-3, f"v{variant} tconv")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (777, 640, 128), (513, 256, 192), (2000, 1280, 1280), (300, 960, 2560), (70000, 320, 640)])
+def test_gemm_k64_ring(M, N, K):
+    """64-deep two-slot ping-pong ring (variant + 200, K % 64 == 0): odd and even tile counts, one to forty K tiles, both tile widths,
+    ragged M, full epilogue; the K order per accumulator equals the 32-deep ring's, so the two must agree bit for bit."""
+    a, w = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4, scale=0.05))
+    bias, res = rnd(N, seed=5), bf(rnd(M, N, seed=7))
+    ref = res.float() + 0.5 * (a.float() @ w.float().T + bias)
+    for v in (211, 231):
+        out = ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=v)
+        close(out, ref, 6e-3, f"v{v} {M}x{N}x{K}")
+        if v == 211:
+            assert torch.equal(out, ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=111)), "64-deep and 32-deep rings differ"
+        for rep in range(3):
+            assert torch.equal(out, ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=v)), f"v{v} run-to-run difference (race)"
+    a1, a2 = a[:, :K - 64].contiguous(), a[:, K - 64:].contiguous()
+    if K > 128:
+        close(ops.gemm(a1, w, a2=a2, bias=bias, variant=211), a.float() @ w.float().T + bias, 6e-3, f"v211 two sources {M}x{N}x{K}")
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, w, variant=141)  # a code that names no geometry is an error, not a silent fallback
 
 
 @pytest.mark.parametrize("variant", [41, 45, 47])
@@ -497,7 +518,7 @@ def test_tconv_halo(variant, B, Fr, hw, cin, cout):
     close(o2, ref2, 8e-3, f"v{variant} halo tconv accumulate")
 
 
-@pytest.mark.parametrize("SPLITK", [20, 25, 45, 120, 125])
+@pytest.mark.parametrize("SPLITK", [20, 25, 45, 120, 125, 225])
 def test_gemm_split_k(SPLITK):
     """Under-filled grids (low-resolution UNet levels, M ~ 1e3, K ~ 1e4) run the K-split ring + deterministic slab
     reduction; same epilogue contract (bias, row-bias, gate, residual, accumulate, fp32 out)."""
