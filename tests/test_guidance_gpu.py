@@ -211,4 +211,37 @@ def test_guidance_step_vs_reference_golden():
         d_ref = torch.from_numpy(g["latents_out" + suffix]).to(DEV) - lat0
         print(f"iters={iters}: loss {float(loss):.4f} vs ref {ref_loss:.4f}; update rel-L2 {rel(d, d_ref):.4f}; |d| {d.abs().mean().item():.3e} vs {d_ref.abs().mean().item():.3e}")
         assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
-        assert rel(d, d_ref) < 0.08
+        assert rel(d, d_ref) < 0.07  # 1.5 x the bf16-storage noise floor of this topology (4.5 %, tests/test_noise_floor.py)
+
+
+@pytest.mark.parametrize("t,layout", [(801, "2obj"), (801, "1box"), (999, "1box")])
+def test_guidance_update_within_bf16_noise_floor(t, layout):
+    """The tolerance of the guidance update is not free-standing.  The fp32 oracle run with bf16 STORAGE of activations and activation
+    gradients (oracle/bf16_storage.py: the rounding points of the product) differs from the plain fp32 oracle by 2.7-4.5 % on these
+    problems: that is the floor any bf16 trunk pays.  The HIP path (bf16 storage, fp32 accumulation, hand-written backward) sits ON that
+    floor: 1.02x on average over 18 (timestep, layout, seed) cases (0.76x .. 1.44x per case — the top-k selections of the energy are
+    discontinuous, so single realisations scatter; tests/probes/noise_floor_probe.py, profiles/r03_noise_floor.txt).  Asserted here over
+    three seeds per case: mean HIP error <= 1.25 x mean floor, every single error <= 2 x the mean floor, and HIP is as close to the
+    bf16-storage oracle as two independent roundings of one computation are (<= 2 x the mean floor)."""
+    from oracle import bf16_storage
+    from test_noise_floor import HP, KEYS, guidance_problem
+    hp = {k: v for k, v in HP.items() if k != "guidance_attn_keys"}
+    floors, errs, errs16 = [], [], []
+    net = None
+    for seed in range(3):
+        cfg, sd, lat, cond, boxes, pos = guidance_problem(seed)
+        if layout == "1box":
+            boxes, pos = [[[0.1, 0.2, 0.6, 0.8]] * lat.shape[2]], [[2]]
+        u32, l32 = bf16_storage.oracle_guidance_update(cfg, sd, lat, cond, boxes, pos, t, "fp32", KEYS, **hp)
+        u16, _ = bf16_storage.oracle_guidance_update(cfg, sd, lat, cond, boxes, pos, t, "bf16", KEYS, **hp)
+        net = net or HipUNet3D(cfg, sd)
+        new, loss = guidance.hip_latent_backward_guidance(scheduler_ref.DPMSolverPP2M(), net, cond.to(DEV), 0, boxes, pos, t, lat.clone().to(DEV),
+                                                          torch.tensor(10000.0), **HP)
+        d = new.cpu() - lat
+        floors.append(rel(u16, u32)); errs.append(rel(d, u32)); errs16.append(rel(d, u16))
+        assert abs(float(loss) - l32) < 1e-2 * abs(l32)
+    mf = sum(floors) / 3
+    print(f"t={t} {layout}: bf16-storage floors {[round(f, 4) for f in floors]}, HIP vs fp32 oracle {[round(e, 4) for e in errs]} "
+          f"(mean ratio {sum(errs) / 3 / mf:.2f}), HIP vs bf16-storage oracle {[round(e, 4) for e in errs16]}")
+    assert sum(errs) / 3 <= 1.25 * mf, (errs, floors)
+    assert max(errs) <= 2.0 * mf and max(errs16) <= 2.0 * mf, (errs, errs16, floors)
