@@ -109,6 +109,8 @@ typedef struct {
   int64_t ws_bytes;
   int32_t m_begin;         /* rows [m_begin, M) are produced (0 = the whole product); row indices stay absolute, so a product
                               can be cut into row ranges (LVD_GEMM_V_*_TAIL variants do this internally) */
+  int32_t ldrowbias;       /* row stride of rowbias in floats (0 = N): the temb projections of all ResnetBlock2Ds of a forward are ONE
+                              product [B, sum of N] and each conv reads its column range of it */
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);
@@ -301,6 +303,9 @@ typedef struct {
   const int32_t* tok_ids; int32_t ntok;
   const float* probs; const float* dprobs; const float* lse;
   lvd_bf16* dq; int32_t lddq;           /* out [frames*P, heads*64] */
+  /* layouts with more object tokens than one launch holds run in chunks of tokens; dQ is linear in them and is summed in fp32:
+     acc_mode 0: dq = value (one launch, acc32 unused)   1: acc32 = value   2: acc32 += value   3: dq = bf16(acc32 + value) */
+  float* acc32; int32_t ldacc; int32_t acc_mode;
 } lvd_ca_dq_params;
 int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream);
 

@@ -235,13 +235,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
     //   phase:      4j        4j+1      4j+2      4j+3
     //   group 0:  L(j,h0)   M(j,h0)   L(j,h1)   M(j,h1)
     //   group 1:  M(j-1,h1) L(j,h0)   M(j,h0)   L(j,h1)
-    // A slot is free once group 1 has read its second half (end of phase 4j+3) and has to hold tile j+2 at phase 4j+8.  A wave's
-    // share of a tile (LPS instructions) goes out in two batches, one per L phase:
+    // A slot is free once group 1 has read its second half AND HAS PASSED THE BARRIER BEHIND THAT PHASE (end of phase 4j+3): the four
+    // waves of a group are not in step inside a phase, so a wave that refilled the slot right behind its own last reads would overwrite
+    // rows a sibling wave is still reading (rare, and only when something else on the CU delays that sibling: a first version did
+    // exactly that and produced a few thousand wrong elements per launch next to a co-tenant process — tests/probes/gemm_cotenant_probe.py).
+    // The slot has to hold tile j+2 at phase 4j+8.  A wave's share of a tile (LPS instructions):
     //   group 0: batch 0 of tile j+1 in L(j,h0), batch 1 in L(j,h1)     -> waits vmcnt(0) behind the MFMAs of M(j,h1)
-    //   group 1: batch 1 of tile j+1 in L(j,h0); batch 0 of tile j+2 at the END of L(j,h1), behind its own last reads of that
-    //            slot (lgkmcnt(0) first)                                  -> waits vmcnt(NB0) there: everything but that batch
-    // RAW: all of tile j+1 is waited for by the end of phase 4j+3, one barrier before its first reader.  WAR: every batch is
-    // issued at least one barrier after the last read of the slot it overwrites (group 1's own reads: after their lgkmcnt(0)).
+    //   group 1: its whole share of tile j+1 in L(j,h0) (phase 4j+1: both groups left that slot two barriers ago); nothing in L(j,h1),
+    //            where a refill would have no phase left to land in    -> waits vmcnt(0) at the end of L(j,h1)
+    // RAW: all of tile j+1 is waited for by the end of phase 4j+3, one barrier before its first reader.  WAR: every batch is issued
+    // at least one barrier after the last read, by any wave, of the slot it overwrites.
     constexpr int NB0 = (LPS + 1) / 2;
     const int group = wave >> 2;
     auto batch0 = [&](int kt, int slot) {
@@ -254,12 +257,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
 #pragma unroll
       for (int idx = NB0; idx < LPS; ++idx) stage_one(kt, slot, idx);
     };
-    if (group == 1 && nk > 1) {
-      batch0(1, 1);
-      wait_vmcnt<NB0>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if constexpr (LDS_BIAS) acc_from_lds_bias();
     if (group == 1) __builtin_amdgcn_s_barrier();
@@ -290,8 +288,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
         }
         if (h == 0) {
           if (j + 1 < nk) {
-            if (group == 0) batch0(j + 1, slot ^ 1);
-            else batch1(j + 1, slot ^ 1);
+            batch0(j + 1, slot ^ 1);
+            if (group == 1) batch1(j + 1, slot ^ 1);
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if (group == 0) {
@@ -299,12 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (j + 2 < nk) {
-            batch0(j + 2, slot);
-            wait_vmcnt<NB0>();
-          } else {
-            wait_vmcnt<0>();
-          }
+          wait_vmcnt<0>();
         }
         LVD_STAMP();
         __builtin_amdgcn_sched_barrier(0);

@@ -169,7 +169,7 @@ LVD_DEV void ring_bias_init(const lvd_gemm_params& p, f32x16 (&acc)[FM][FN], con
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = min(rm(i * 32 + l31), p.M - 1);
-      const float* rb = p.rowbias + (long)(m / p.rows_per_sample) * p.N;
+      const float* rb = p.rowbias + (long)(m / p.rows_per_sample) * (p.ldrowbias ? p.ldrowbias : p.N);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -411,7 +411,7 @@ inline int lvd_splitk_plan(long tiles, int K, int slots, int slab_cost, long* co
 LVD_DEV void splitk_reduce_quad(const lvd_gemm_params& p, const float* s0, long sstride, int m, int n) {
   const float* safe = p.ws;
   const float* bp = p.bias ? p.bias + n : safe;
-  const float* rbp = p.rowbias ? p.rowbias + (long)(m / (p.rows_per_sample > 0 ? p.rows_per_sample : 1)) * p.N + n : safe;
+  const float* rbp = p.rowbias ? p.rowbias + (long)(m / (p.rows_per_sample > 0 ? p.rows_per_sample : 1)) * (p.ldrowbias ? p.ldrowbias : p.N) + n : safe;
   const lvd_bf16* rp = p.res ? p.res + (long)m * p.ldres + n : reinterpret_cast<const lvd_bf16*>(safe);
   float* of = reinterpret_cast<float*>(p.out) + (long)m * p.ldc + n;
   lvd_bf16* ob = reinterpret_cast<lvd_bf16*>(p.out) + (long)m * p.ldc + n;

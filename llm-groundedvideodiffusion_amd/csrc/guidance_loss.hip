@@ -430,14 +430,27 @@ __global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
   }
   if (qi < p.P) {
     lvd_bf16* op = p.dq + ((long)f * p.P + qi) * p.lddq + h * 64 + 4 * hi;
+    float* ap = p.acc32 + ((long)f * p.P + qi) * p.ldacc + h * 64 + 4 * hi;  // token chunks are summed in fp32 (acc_mode, lvdhip.h)
     const float fs = p.scale;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
-      uint2 w0, w1;
-      w0.x = pack2bf(dq0[rq * 4 + 0] * fs, dq0[rq * 4 + 1] * fs); w0.y = pack2bf(dq0[rq * 4 + 2] * fs, dq0[rq * 4 + 3] * fs);
-      w1.x = pack2bf(dq1[rq * 4 + 0] * fs, dq1[rq * 4 + 1] * fs); w1.y = pack2bf(dq1[rq * 4 + 2] * fs, dq1[rq * 4 + 3] * fs);
-      stg8(op + 8 * rq, w0);
-      stg8(op + 32 + 8 * rq, w1);
+      f32x4 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = dq0[rq * 4 + e] * fs; v1[e] = dq1[rq * 4 + e] * fs; }
+      if (p.acc_mode >= 2) {
+        v0 += *reinterpret_cast<const f32x4*>(ap + 8 * rq);
+        v1 += *reinterpret_cast<const f32x4*>(ap + 32 + 8 * rq);
+      }
+      if (p.acc_mode == 1 || p.acc_mode == 2) {
+        *reinterpret_cast<f32x4*>(ap + 8 * rq) = v0;
+        *reinterpret_cast<f32x4*>(ap + 32 + 8 * rq) = v1;
+      } else {
+        uint2 w0, w1;
+        w0.x = pack2bf(v0[0], v0[1]); w0.y = pack2bf(v0[2], v0[3]);
+        w1.x = pack2bf(v1[0], v1[1]); w1.y = pack2bf(v1[2], v1[3]);
+        stg8(op + 8 * rq, w0);
+        stg8(op + 32 + 8 * rq, w1);
+      }
     }
   }
 }
@@ -472,6 +485,7 @@ extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) {
 extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) {
   LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->dprobs && p->lse && p->dq, "ca_dq: null pointer");
   LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_dq: ntok=%d outside 1..%d", p->ntok, MAXTOK);
+  LVD_CHECK(p->acc_mode >= 0 && p->acc_mode <= 3 && (p->acc_mode == 0 || (p->acc32 && p->ldacc % 4 == 0)), "ca_dq: acc_mode %d needs an fp32 accumulator", p->acc_mode);
   dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
   hipLaunchKernelGGL(ca_dq_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
   LVD_LAUNCH_CHECK();

@@ -137,6 +137,17 @@ class HipUNet3D:
             p = name[: -len(".weight")]
             w[p + ".weight"], w[p + ".bias"] = interleave_geglu(w[p + ".weight"], w[p + ".bias"])
         self.cross_layers = sorted(n[: -len(".to_kv.weight")] for n in w if n.endswith(".to_kv.weight"))
+        # the time-embedding projections of all ResnetBlock2Ds read the same [B, 1280] input: ONE product [B, sum of Cout] per forward
+        # instead of 22 two-row GEMM launches; each conv1 reads its column range (lvd_gemm_params.ldrowbias)
+        tnames = sorted(n[: -len(".time_emb_proj.weight")] for n in w if n.endswith(".time_emb_proj.weight"))
+        self.temb_slices, off = {}, 0
+        for n in tnames:
+            co = w[n + ".time_emb_proj.weight"].shape[0]
+            self.temb_slices[n] = (off, off + co)
+            off += co
+        if tnames:
+            w["time_emb_proj_all.weight"] = torch.cat([w.pop(n + ".time_emb_proj.weight") for n in tnames], 0).contiguous()
+            w["time_emb_proj_all.bias"] = torch.cat([w.pop(n + ".time_emb_proj.bias") for n in tnames], 0).contiguous()
 
     def wt(self, name, kind="linear"):
         """Lazily built input-gradient layout of a packed weight (kept resident: 288 GB of HBM)."""
@@ -417,11 +428,11 @@ class HipUNet3D:
         hs = self._transformer_block(hs, name + ".transformer_blocks.0", heads, tape=tape, spatial=False, g=g)
         return self._linear(hs, name + ".proj_out", tape=tape, res=x)
 
-    def _resnet(self, x, name, g: Geom, temb_act, *, tape, skip=None):
+    def _resnet(self, x, name, g: Geom, temb_rows, *, tape, skip=None):
         eps = self.cfg.norm_eps
         h = self._groupnorm(x, name + ".norm1", g.HW, tape=tape, eps=eps, silu=True, x2=skip)
-        rb = ops.gemm(temb_act, self.w[name + ".time_emb_proj.weight"], bias=self.w[name + ".time_emb_proj.bias"], out_fp32=True)
-        h, _ = self._conv3x3(h, name + ".conv1", g, tape=tape, rowbias=rb)
+        a, b = self.temb_slices[name]
+        h, _ = self._conv3x3(h, name + ".conv1", g, tape=tape, rowbias=temb_rows[:, a:b])
         h = self._groupnorm(h, name + ".norm2", g.HW, tape=tape, eps=eps, silu=True)
         if (name + ".conv_shortcut.weight") in self.w:
             sc = self._linear(x, name + ".conv_shortcut", tape=tape, x2=skip)
@@ -480,7 +491,8 @@ class HipUNet3D:
             t = torch.full((B,), float(timestep), dtype=torch.float32, device=self.dev)
         temb = ops.timestep_embedding(t, boc[0])
         emb = self._linear(ops.silu(self._linear(temb, "time_embedding.linear_1", tape=None)), "time_embedding.linear_2", tape=None)
-        temb_act = ops.silu(emb)  # every ResnetBlock2D applies SiLU to temb first
+        # every ResnetBlock2D applies SiLU to temb first, then its own projection: all projections in one product [B, sum of Cout] fp32
+        temb_rows = ops.gemm(ops.silu(emb), self.w["time_emb_proj_all.weight"], bias=self.w["time_emb_proj_all.bias"], out_fp32=True)
 
         tokens = ops.latents_to_tokens(sample, cpad=8)
         x, _ = self._conv3x3(tokens, "conv_in", g, tape=tape)
@@ -490,7 +502,7 @@ class HipUNet3D:
             objs = self.position_net(gligen["boxes"], gligen["masks"], gligen["positive_embeddings"])
 
         def layer(prefix, j, key, x, g, has_attn, c, skip=None):
-            x = self._resnet(x, f"{prefix}.resnets.{j}", g, temb_act, tape=tape, skip=skip)
+            x = self._resnet(x, f"{prefix}.resnets.{j}", g, temb_rows, tape=tape, skip=skip)
             x = self._temporal_conv(x, f"{prefix}.temp_convs.{j}", g, tape=tape)
             if has_attn:
                 x = self._transformer2d(x, f"{prefix}.attentions.{j}", c // dh, g, text, tape=tape, objs=objs, key=key, collect=collect)
@@ -508,11 +520,11 @@ class HipUNet3D:
                     x, g = self._conv3x3(x, f"down_blocks.{i}.downsamplers.0.conv", g, tape=tape, stride=2)
                     skips.append((x, g))
             c = boc[-1]
-            x = self._resnet(x, "mid_block.resnets.0", g, temb_act, tape=tape)
+            x = self._resnet(x, "mid_block.resnets.0", g, temb_rows, tape=tape)
             x = self._temporal_conv(x, "mid_block.temp_convs.0", g, tape=tape)
             x = self._transformer2d(x, "mid_block.attentions.0", c // dh, g, text, tape=tape, objs=objs, key=("mid", 0, 0, 0), collect=collect)
             x = self._transformer_temporal(x, "mid_block.temp_attentions.0", c // dh, g, tape=tape)
-            x = self._resnet(x, "mid_block.resnets.1", g, temb_act, tape=tape)
+            x = self._resnet(x, "mid_block.resnets.1", g, temb_rows, tape=tape)
             x = self._temporal_conv(x, "mid_block.temp_convs.1", g, tape=tape)
             rev = list(reversed(boc))
             for i, btype in enumerate(cfg.up_block_types):

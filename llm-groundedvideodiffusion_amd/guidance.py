@@ -85,26 +85,30 @@ MAX_TOKENS_PER_LAUNCH = 16  # csrc/guidance_loss.hip MAXTOK: object-token column
 
 def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext, grad_scale, fg_weight, bg_weight,
                           com_loss_scale, loss_partial, want_dq=True, use_ratio_based_loss=False, attn_sync_weight=0.0,
-                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1):
+                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, _acc=None):
     """One guidance key: q [frames*P, heads*64] bf16, k [ntext, heads*64] bf16 (strided ok).
 
     Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ.  Layouts with
     more object tokens than one launch holds run in chunks of tokens: the loss terms are per token and dQ is linear in them."""
     if layout.ntok and int(layout.tok_ids_host.max()) >= ntext:  # the reference indexes attn[..., pos] and raises the same way
         raise IndexError(f"object token position {int(layout.tok_ids_host.max())} is out of bounds for {ntext} text tokens")
-    if layout.ntok > MAX_TOKENS_PER_LAUNCH:
-        dq_total, off = None, 0
-        for c0 in range(0, layout.ntok, MAX_TOKENS_PER_LAUNCH):
+    if layout.ntok > MAX_TOKENS_PER_LAUNCH and _acc is None:
+        # dQ is linear in the tokens: the chunks are summed in an fp32 accumulator by the dq kernel itself (first chunk stores, middle
+        # chunks add, the last one adds and rounds to bf16 once)
+        starts = list(range(0, layout.ntok, MAX_TOKENS_PER_LAUNCH))
+        acc32 = torch.empty((q.shape[0], q.shape[1]), dtype=torch.float32, device=q.device) if want_dq else None
+        dq, off = None, 0
+        for ci, c0 in enumerate(starts):
             sub = layout.token_slice(c0, min(layout.ntok, c0 + MAX_TOKENS_PER_LAUNCH))
             n = frames * heads * sub.ntok
+            mode = 1 if ci == 0 else (3 if ci == len(starts) - 1 else 2)
             dq = ca_energy_loss_and_dq(q, k, heads, frames, sub, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
                                        com_loss_scale=com_loss_scale, loss_partial=loss_partial[off:off + n], want_dq=want_dq,
                                        use_ratio_based_loss=use_ratio_based_loss, attn_sync_weight=attn_sync_weight,
-                                       boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed, boxdiff_L=boxdiff_L)
+                                       boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed, boxdiff_L=boxdiff_L,
+                                       _acc=(acc32, mode))
             off += n
-            if want_dq:
-                dq_total = dq if dq_total is None else ops.add(dq_total, dq, out=dq_total)
-        return dq_total
+        return dq
     dev = q.device
     P = layout.H * layout.W
     assert q.shape[0] == frames * P, (q.shape, frames, P)
@@ -132,13 +136,19 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
     hip.check(hip.lib().lvdhip_ca_select(C.byref(b), st), "ca_select")
     if not want_dq:
         return None
-    dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev)
+    acc32, mode = _acc if _acc is not None else (None, 0)
+    dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev) if mode in (0, 3) else None
     c = hip.CaDqParams()
     c.q, c.ldq, c.k, c.ldk = a.q, a.ldq, a.k, a.ldk
     c.frames, c.heads, c.P, c.ntext, c.scale = frames, heads, P, ntext, 0.125
     c.tok_ids, c.ntok = a.tok_ids, a.ntok
     c.probs, c.dprobs, c.lse = probs.data_ptr(), dprobs.data_ptr(), lse.data_ptr()
-    c.dq, c.lddq = dq.data_ptr(), dq.stride(0)
+    if dq is not None:
+        c.dq, c.lddq = dq.data_ptr(), dq.stride(0)
+    else:  # accumulate-only chunk: the bf16 output is not written (any valid pointer)
+        c.dq, c.lddq = acc32.data_ptr(), 0
+    if acc32 is not None:
+        c.acc32, c.ldacc, c.acc_mode = acc32.data_ptr(), acc32.stride(0), mode
     hip.check(hip.lib().lvdhip_ca_dq(C.byref(c), st), "ca_dq")
     return dq
 

@@ -27,7 +27,7 @@ class GemmParams(C.Structure):
         ("hin", i32), ("win", i32), ("hout", i32), ("wout", i32), ("stride", i32), ("upsample", i32),
         ("frames", i32), ("hw", i32), ("rows_per_sample", i32), ("ldres", i32), ("ldc", i32),
         ("act", i32), ("out_fp32", i32), ("alpha", f32), ("accumulate", i32), ("variant", i32),
-        ("ksplit", i32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("m_begin", i32),
+        ("ksplit", i32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("m_begin", i32), ("ldrowbias", i32),
     ]
 
 
@@ -132,6 +132,7 @@ class CaDqParams(C.Structure):
         ("tok_ids", C.c_void_p), ("ntok", i32),
         ("probs", C.c_void_p), ("dprobs", C.c_void_p), ("lse", C.c_void_p),
         ("dq", C.c_void_p), ("lddq", i32),
+        ("acc32", C.c_void_p), ("ldacc", i32), ("acc_mode", i32),
     ]
 
 

@@ -54,6 +54,11 @@ def _chk_f32(*ts):
             assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), "contiguous fp32 CUDA tensor expected"
 
 
+def _chk_f32_rows(t):
+    if t is not None:
+        assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.stride(1) == 1, "fp32 CUDA matrix with contiguous rows expected"
+
+
 @dataclass
 class ConvGeom:
     hin: int
@@ -77,16 +82,22 @@ HALO_VARIANTS = (41, 45, 47)  # conv_halo.hip: whole grid / channel-chunk split-
 _splitk_ws = {}
 
 
+SPLITK_WS_BYTES = int(os.environ.get("LVD_SPLITK_WS_MB", "1024")) << 20
+
+
 def _splitk_workspace(dev, nbytes):
-    """One grow-only fp32 workspace per device for the split-K slabs (stream-ordered reuse is safe: every user is a
-    GEMM+reduce pair on the same stream)."""
+    """ONE fp32 workspace per device for the K-split slabs, of a FIXED size (stream-ordered reuse is safe: every user is a GEMM+reduce
+    pair on the same stream).  The K-split plans of the library are functions of the workspace size they are offered (a plan that does
+    not fit takes fewer slices or falls back to the unsplit launch), so the size must not depend on what a process happened to run
+    before: a grow-only buffer made a sharded run (table loaded, nothing tuned, small buffer) pick other plans — other fp32 summation
+    orders, other bf16 bits — than the single-process run that had grown it while tuning."""
     ws = _splitk_ws.get(dev)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((max(nbytes, 64 << 20) + 3) // 4, dtype=torch.float32, device=dev)
-        _splitk_ws[dev] = ws
+    if ws is None:
+        ws = _splitk_ws[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev)
     return ws
 _gemm_choice = {}
 _autotune = {"enabled": True, "min_flops": 2e9}
+_EXCLUDE = tuple(int(v) for v in os.environ.get("LVD_GEMM_EXCLUDE", "").split(",") if v)  # developer knob: variants the tuner must not try
 
 
 def set_gemm_autotune(enabled: bool):
@@ -128,6 +139,8 @@ def _tune_gemm(p, key, out):
     if halo and not p.a2 and p.cin % 32 == 0:
         cands += (HALO_VARIANTS if p.ws else HALO_VARIANTS[:1])  # LDS-resident im2col (conv_halo.hip)
     for v in cands:
+        if v in _EXCLUDE:
+            continue
         p.variant = v
         _launch_gemm(p)  # warm-up (also instruction-cache / L2)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
@@ -141,6 +154,9 @@ def _tune_gemm(p, key, out):
             best, best_t = v, t
     p.out, p.accumulate = saved_out, saved_acc
     _gemm_choice[key] = best
+    if os.environ.get("LVD_GEMM_LOG"):  # developer knob: which shapes a process had to tune (none, when a complete table was loaded)
+        import sys
+        print(f"[lvd gemm autotune] {key} -> {best}", file=sys.stderr, flush=True)
     return best
 
 
@@ -149,7 +165,8 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
          alpha=1.0, accumulate=False, m=None, variant=0, m_begin=0):
     """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`.  `m_begin` > 0 produces rows [m_begin, M) only."""
     _chk_bf16(a1, a2, w, res)
-    _chk_f32(bias, rowbias)
+    _chk_f32(bias)
+    _chk_f32_rows(rowbias)  # may be a column range of a wider matrix (engine: all temb projections of a forward are one product)
     N, K = w.shape if (n is None or k is None) else (n, k)
     assert w.is_contiguous()
     c1 = a1.shape[1]
@@ -173,6 +190,7 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
         p.hin, p.win, p.hout, p.wout, p.stride, p.upsample = conv.hin, conv.win, conv.hout, conv.wout, conv.stride, conv.upsample
     p.frames, p.hw = frames, hw
     p.rows_per_sample = rows_per_sample
+    p.ldrowbias = rowbias.stride(0) if rowbias is not None else 0
     p.ldres = _ld(res) if res is not None else 0
     p.ldc = _ld(out)
     p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
@@ -180,7 +198,7 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     need = C.c_int64(0)
     hip.check(hip.lib().lvdhip_gemm_workspace_bytes(C.byref(p), C.byref(need)), "gemm_workspace_bytes")
     if need.value:
-        ws = _splitk_workspace(a1.device, need.value)  # one grow-only buffer per device, shared by all launches of the stream
+        ws = _splitk_workspace(a1.device, need.value)  # one fixed-size buffer per device, shared by all launches of the stream
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"]:
         # everything a candidate's eligibility or cost depends on: the conv image (the LDS-resident tap GEMM needs W <= 87), the temporal

@@ -151,3 +151,62 @@ def test_gated_full_size_properties(full_gated):
     finally:
         net.alpha.update(saved)
     assert rel(zero, off) < 2e-3, rel(zero, off)
+
+
+def test_lvd_plus_full_size_step_properties(full_gated):
+    """BASELINE configs[4] (lvd_plus zeroscope 576x320x24: guidance + GLIGEN adapters), ONE full-size step of its loop
+    (/root/reference/generation/lvd_plus.py:75-210, models/pipelines.py:66-82): the guidance iteration runs on the GATED weights with the
+    fusers skipped, then the CFG forward runs with the fusers on, then the fused CFG / DPM-Solver++ update.  No oracle finishes at this
+    size, so size-independent properties:
+      (i)   fusers skipped == fusers absent: loss and latent gradient of the guidance pass on the gated engine equal, bit for bit, those of
+            an engine built from the same weights without the fuser parameters;
+      (ii)  descent: the energy at the updated latents is lower than at the input latents;
+      (iii) the CFG forward with the fusers on is finite and differs from the fusers-off forward; the fused update equals the host formula
+            x' = c_x x + c_0 x0 + c_1 x0_prev with x0 = (x - sigma eps) / alpha on the same eps."""
+    from lvd_amd import ops
+    from lvd_amd.sampler import DPMSolverPP2MSchedule, HipSampler
+    cfg, net, sd = full_gated
+    gen = torch.Generator().manual_seed(6)
+    Fr = 24
+    lat = torch.randn(1, 4, Fr, 40, 72, generator=gen).cuda()
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen).cuda()
+    keys = [("down", 1, 0, 0), ("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 2, 0)]
+    bear = [[0.0 + 0.8301 * f / 23, 0.5, 0.1953 + 0.8301 * f / 23, 0.6953] for f in range(Fr)]
+    ball = [([0.45, 0.7, 0.6, 0.9] if not 9 <= f < 15 else [0.0] * 4) for f in range(Fr)]
+    boxes, pos = [bear, ball], [[2], [7, 8]]
+    hp = dict(loss_scale=2.5, fg_top_p=0.25, bg_top_p=0.25, fg_weight=1.0, bg_weight=2.0)
+    text_cond = net.encode_text(ehs[1:2])
+    t = 801
+    loss, grad = guidance.guidance_loss_and_grad(net, lat, t, text_cond, boxes, pos, keys, **hp)
+    assert torch.isfinite(loss).all() and torch.isfinite(grad).all() and float(grad.abs().max()) > 0
+    # (i) the same weights without the adapters
+    plain_cfg = UNetConfig()
+    plain_sd = {k: v for k, v in sd.items() if ".fuser." not in k and not k.startswith("position_net.")}
+    plain = HipUNet3D(plain_cfg, plain_sd, device="cuda")
+    loss_p, grad_p = guidance.guidance_loss_and_grad(plain, lat, t, plain.encode_text(ehs[1:2]), boxes, pos, keys, **hp)
+    assert torch.equal(loss, loss_p) and torch.equal(grad, grad_p), (float(loss), float(loss_p), rel(grad, grad_p))
+    del plain
+    # (ii) descent along the update the reference applies (latents - sqrt(1 - alpha_bar_t) * grad, models/pipelines.py:124-132)
+    sched = DPMSolverPP2MSchedule.from_ddim_config()
+    sched.set_timesteps(40)
+    lat2 = ops.axpy_(lat.clone(), grad, float((1 - sched.alphas_cumprod[t]) ** 0.5))
+    loss2, _ = guidance.guidance_loss_and_grad(net, lat2, t, text_cond, boxes, pos, keys, **hp)
+    print(f"lvd_plus full-size step: energy {float(loss):.4f} -> {float(loss2):.4f} after the guidance update")
+    assert float(loss2) < float(loss)
+    # (iii) gated CFG forward (fusers on) + fused update
+    gl = _gligen_inputs(cfg, 2, Fr, 2, gen)
+    text_cfg = net.encode_text(ehs)
+    x2 = lat2.expand(2, -1, -1, -1, -1).contiguous()
+    eps = net.forward(x2, int(sched.timesteps[1]), text=text_cfg, gligen=gl)
+    eps_off = net.forward(x2, int(sched.timesteps[1]), text=text_cfg, gligen=gl, fuser_enabled=False)
+    assert torch.isfinite(eps).all() and rel(eps[1:2], eps_off[1:2]) > 1e-2
+    sampler = HipSampler(net, sched, guidance_scale=9.0)
+    sampler.reset(lat2)
+    sched.step_index, sched.lower_order_nums = 1, 1
+    x0_prev = torch.randn(lat2.shape, generator=torch.Generator().manual_seed(7)).cuda()
+    sampler.x0_prev.copy_(x0_prev)
+    a_t, s_t, c_x, c_0, c_1 = sched.coefficients(1)
+    e = eps[0:1] + 9.0 * (eps[1:2] - eps[0:1])
+    want = c_x * lat2 + c_0 * ((lat2 - s_t * e) / a_t) + c_1 * x0_prev
+    got = sampler.cfg_step(lat2.clone(), 1, text_cfg, gligen=gl)
+    assert rel(got, want) < 1e-5, rel(got, want)
