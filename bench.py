@@ -100,10 +100,32 @@ class GemmTimer:
         return agg
 
 
-def cpu_baseline(sd_cpu, cfg, budget_s=25.0):
-    """fp32 oracle (restatement of the reference, oracle/) on the host cores, three bounded legs:
-      A. BASELINE config 0 end to end: 256x144x8 (latent 18x32), DPM-Solver++ CFG sampling loop, 10 steps (stops early when
-         the leg's time budget is spent; the steps are identical work, the per-step time is what is reported);
+def _pick_threads(sd_cpu, cfg, ehs, g):
+    """The oracle is memory- and launch-bound on many-core hosts: all hardware threads is rarely the fastest setting (round 2 ran 128
+    threads at 0.11-0.21 TFLOP/s where 8 cores reach 0.6).  One small CFG forward per candidate thread count, keep the fastest."""
+    from oracle import unet_ref
+    hw = os.cpu_count() or 8
+    cands = sorted({c for c in (8, 16, 32, 64) if 1 <= c <= hw} or {hw})  # beyond 64 the probe itself takes minutes on a 256-thread host (128: 18 s, 256: 343 s)
+    x = torch.randn(2, 4, 4, 18, 32, generator=g)
+    timings = {}
+    with torch.no_grad():
+        torch.set_num_threads(cands[-1])
+        unet_ref.unet_forward(sd_cpu, cfg, x, 500, ehs)  # page the weights in once, outside the comparison
+        for c in cands:
+            torch.set_num_threads(c)
+            t0 = time.time()
+            unet_ref.unet_forward(sd_cpu, cfg, x, 500, ehs)
+            timings[c] = time.time() - t0
+    best = min(timings, key=timings.get)
+    torch.set_num_threads(best)
+    return best, {str(k): round(v, 2) for k, v in timings.items()}
+
+
+def cpu_baseline(sd_cpu, cfg, budget_s=25.0, loop_budget_s=70.0):
+    """fp32 oracle (restatement of the reference, oracle/) on the host cores, three bounded legs, at the thread count that
+    maximises its throughput (measured first, printed):
+      A. BASELINE config 0 end to end: 256x144x8 (latent 18x32), DPM-Solver++ CFG sampling loop, all 10 steps unless the leg's own budget
+         (`loop_budget_s`, stated in the line) runs out — the steps are identical work, the per-step time is what is reported;
       B. ONE CFG UNet forward at the largest of (8x18x32, 12x24x40, 16x32x32, 24x40x72) predicted to fit the budget;
       C. ONE guidance iteration (cond-branch forward with saved attention maps + compute_ca_loss + autograd backward to the
          latents) at the largest size predicted to fit the budget — a different FLOP/s regime than a forward.
@@ -111,10 +133,10 @@ def cpu_baseline(sd_cpu, cfg, budget_s=25.0):
     each leg with its own measured rate; every extrapolation factor is spelled out in `sample`."""
     from oracle import guidance_ref, scheduler_ref, unet_ref
     g = torch.Generator().manual_seed(0)
-    cores = torch.get_num_threads()
     fl_per_cell = TF_CFG_FWD / (2 * FRAMES * LAT_H * LAT_W)       # TFLOP per (batch item, frame, latent pixel) of a forward
     gfl_per_cell = TF_GUIDANCE_ITER / (FRAMES * LAT_H * LAT_W)    # guidance iteration (fwd to the last key + backward), B=1
     ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    cores, thread_probe = _pick_threads(sd_cpu, cfg, ehs, g)
 
     # ---- A: config 0 loop
     sch = scheduler_ref.DPMSolverPP2M()
@@ -127,7 +149,7 @@ def cpu_baseline(sd_cpu, cfg, budget_s=25.0):
             eps = unet_ref.unet_forward(sd_cpu, cfg, lat.expand(2, -1, -1, -1, -1), int(t), ehs)
             lat = sch.step(eps[0:1] + 9.0 * (eps[1:2] - eps[0:1]), lat)
             done += 1
-            if time.time() - t0 > budget_s:
+            if time.time() - t0 > loop_budget_s:
                 break
     t_a = (time.time() - t0) / done
     tf_a = 2 * 8 * 18 * 32 * fl_per_cell
@@ -166,11 +188,12 @@ def cpu_baseline(sd_cpu, cfg, budget_s=25.0):
 
     t_guided = TF_CFG_FWD / rate_b + TF_GUIDANCE_ITER / rate_c
     return {"value": round(FRAMES / t_guided, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "legs": {"config0_loop": {"steps_run": done, "of": 10, "s_per_step": round(t_a, 2), "tflops": round(rate_fwd, 3),
+            "host_threads_available": os.cpu_count(), "thread_probe_s": thread_probe,
+            "legs": {"config0_loop": {"steps_run": done, "of": 10, "budget_s": loop_budget_s, "s_per_step": round(t_a, 2), "tflops": round(rate_fwd, 3),
                                       "frames_per_s": round(8 / t_a, 3), "workload": "256x144x8, CFG DPM-Solver++ step, fp32"},
                      "cfg_forward": {"frames_h_w": list(fb), "s": round(t_b, 2), "tflop": round(tf_b, 2), "tflops": round(rate_b, 3)},
                      "guidance_iteration": {"frames_h_w": list(fc), "s": round(t_c, 2), "tflop": round(tf_c, 2), "tflops": round(rate_c, 3)}},
-            "sample": f"fp32 oracle on {cores} threads: (A) config 0 loop 256x144x8: {done}/10 CFG steps, {t_a:.1f} s/step = {rate_fwd:.3f} TFLOP/s; "
+            "sample": f"fp32 oracle on {cores} threads (fastest of {thread_probe} s per probe forward): (A) config 0 loop 256x144x8: {done}/10 CFG steps, {t_a:.1f} s/step = {rate_fwd:.3f} TFLOP/s; "
                       f"(B) one CFG forward at {fb[0]}x{fb[1]}x{fb[2]} latents ({tf_b:.2f} TFLOP) {t_b:.1f} s = {rate_b:.3f} TFLOP/s; "
                       f"(C) one guidance iteration with autograd at {fc[0]}x{fc[1]}x{fc[2]} ({tf_c:.2f} TFLOP) {t_c:.1f} s = {rate_c:.3f} TFLOP/s; "
                       f"guided 576x320x24 step extrapolated by algorithmic FLOPs: {TF_CFG_FWD}/{rate_b:.3f} + {TF_GUIDANCE_ITER}/{rate_c:.3f} s = {t_guided:.0f} s"}
@@ -185,6 +208,13 @@ def main():
     ap.add_argument("--unguided-steps", type=int, default=4, help="extra (untimed-for-value) unguided steps for the breakdown")
     ap.add_argument("--gligen", action="store_true", help="BASELINE config 3 instead of the default config 2: gated topology (1624M params), "
                     "GLIGEN fusers on in the CFG forward (52.88 TFLOP); not the headline metric")
+    ap.add_argument("--gemm_autotune_table", default=os.path.join(ROOT, "profiles", "gemm_autotune_576x320x24.json"),
+                    help="per-shape GEMM tile-geometry choices (shipped: measured once on MI355X): the same kernels, and the same bf16 bits, in every "
+                         "run and rank; shapes the table does not hold are tuned on first use")
+    ap.add_argument("--retune", action="store_true", help="ignore the table and time the candidates again (--save_autotune_table writes the result)")
+    ap.add_argument("--save_autotune_table", default=None)
+    ap.add_argument("--videos-per-gpu", type=int, default=1, help="throughput mode, NOT the headline: V independent (prompt, seed) samples per GPU, "
+                    "their CFG forwards batched (B = 2V); guidance stays one recorded pass per sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,6 +233,11 @@ def main():
             dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
 
+    table_loaded = None
+    if not args.retune and args.gemm_autotune_table and os.path.exists(args.gemm_autotune_table):
+        ops.load_gemm_autotune_table(args.gemm_autotune_table)
+        table_loaded = os.path.relpath(args.gemm_autotune_table, ROOT)
+    V = args.videos_per_gpu
     cfg = UNetConfig(attention_type="gated") if args.gligen else UNetConfig()
     sd = synthetic_state_dict(cfg, seed=0, device=dev)
     engine = HipUNet3D(cfg, sd, device=dev)
@@ -216,6 +251,14 @@ def main():
     ehs = torch.randn(2, 77, cfg.cross_attention_dim, device=dev, generator=g)  # [negative; positive]
     text_cfg = engine.encode_text(ehs)
     text_cond = engine.encode_text(ehs[1:2])
+    # throughput mode: V - 1 further samples with their own latents and prompts; CFG batch = [uncond_0, cond_0, uncond_1, cond_1, ...]
+    more = [(torch.randn(1, 4, FRAMES, LAT_H, LAT_W, device=dev, generator=g), torch.randn(2, 77, cfg.cross_attention_dim, device=dev, generator=g))
+            for _ in range(V - 1)]
+    if V > 1:
+        assert not args.gligen, "--videos-per-gpu with --gligen is not wired"
+        text_cfg_all = engine.encode_text(torch.cat([ehs] + [e for _, e in more]))
+        text_cond_more = [engine.encode_text(e[1:2]) for _, e in more]
+        x0_prev_more = [torch.zeros_like(l) for l, _ in more]
     bboxes, positions = demo_layout()
     gligen = None
     if args.gligen:  # controllable_pipeline_text_to_video_synth.py:736-814: 30 slots per frame, [unconditional; conditional]
@@ -232,20 +275,46 @@ def main():
 
     state = {"i": 0}
 
+    gkw = dict(loss_scale=hp["loss_scale"], loss_threshold=0.0, max_iter=1, max_index_step=10, guidance_attn_keys=GUIDANCE_KEYS,
+               **{k: v for k, v in hp.items() if k != "loss_scale"})
+
+    def cfg_all(i):
+        """CFG forward + fused update of all V samples in one batch-2V pass."""
+        t = int(sched.timesteps[i])
+        lats = [latents] + [l for l, _ in more]
+        x = torch.cat([l.expand(2, -1, -1, -1, -1) for l in lats]).contiguous()
+        eps = engine.forward(x, t, text=text_cfg_all)
+        a_t, s_t, c_x, c_0, c_1 = sched.coefficients(i)
+        for v, (l, xp) in enumerate(zip(lats, [sampler.x0_prev] + x0_prev_more)):
+            ops.cfg_dpm_step(eps[2 * v:2 * v + 1], eps[2 * v + 1:2 * v + 2], sampler.guidance_scale, l, xp, a_t, s_t, c_x, c_0, c_1)
+        sched.advance()
+
     def guided_step():
+        """The product's own step: `hip_latent_backward_guidance` (recorded forward, fused loss, hand-written backward, latent update; the
+        reference's loss.item() of models/pipelines.py:134 is read by the next step's entry check) followed by the CFG forward and the
+        fused CFG / DPM-Solver++ update."""
         i = state["i"] % 10  # guidance is active for step indices < max_index_step=10
         sched.step_index, sched.lower_order_nums = i, min(i, 2)
         t = int(sched.timesteps[i])
-        loss, grad = guidance.guidance_loss_and_grad(engine, latents, t, text_cond, bboxes, positions, GUIDANCE_KEYS, **hp)
-        ops.axpy_(latents, grad, float((1 - sched.alphas_cumprod[t]) ** 0.5))
-        sampler.cfg_step(latents, i, text_cfg, gligen=gligen)
+        new, loss = guidance.hip_latent_backward_guidance(sched, engine, text_cond, i, bboxes, positions, t, latents, 10000.0, **gkw)
+        latents.copy_(new)
+        for (l, _), tc in zip(more, text_cond_more if V > 1 else []):
+            nl, _ = guidance.hip_latent_backward_guidance(sched, engine, tc, i, bboxes, positions, t, l, 10000.0, **gkw)
+            l.copy_(nl)
+        if V > 1:
+            cfg_all(i)
+        else:
+            sampler.cfg_step(latents, i, text_cfg, gligen=gligen)
         state["i"] += 1
         return loss
 
     def unguided_step():
         i = 10 + state["i"] % 29
         sched.step_index, sched.lower_order_nums = i, 2
-        sampler.cfg_step(latents, i, text_cfg, gligen=gligen)  # --gligen: fusers on, as in steps 10..15 of the 40 (beta = 0.4)
+        if V > 1:
+            cfg_all(i)
+        else:
+            sampler.cfg_step(latents, i, text_cfg, gligen=gligen)  # --gligen: fusers on, as in steps 10..15 of the 40 (beta = 0.4)
         state["i"] += 1
 
     def sync():
@@ -256,13 +325,17 @@ def main():
 
     def keep_finite():
         # random-init weights are not a denoiser: re-draw the latents so timing never runs on inf/nan (untimed)
-        if not bool(torch.isfinite(latents).all()) or float(latents.abs().max()) > 50:
-            latents.copy_(torch.randn(latents.shape, device=dev, generator=g))
+        for l in [latents] + [m for m, _ in more]:
+            if not bool(torch.isfinite(l).all()) or float(l.abs().max()) > 50:
+                l.copy_(torch.randn(l.shape, device=dev, generator=g))
+        if not bool(torch.isfinite(sampler.x0_prev).all()):
             sampler.reset(latents)
 
-    guided_step()  # untimed preparation, independent of --warmup: the GEMM autotuner picks a variant per shape on first use
+    guided_step()  # untimed preparation, independent of --warmup: shapes the autotune table does not hold are tuned on first use
     unguided_step()
     keep_finite()
+    if args.save_autotune_table and rank == 0:
+        ops.save_gemm_autotune_table(args.save_autotune_table)
     for _ in range(args.warmup):
         guided_step()
         keep_finite()
@@ -314,6 +387,7 @@ def main():
         ach = fl / secs / 1e12
         traffic, tnote = None, "no profiles/r02_gemm_traffic.json next to bench.py"
         tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        tsource = "profiles/r02_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes of tools/gemm_pmc.py; NOT measured in this run)"
         if os.path.exists(tpath):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py, rolled up by tools/pmc_traffic.py
             tj = json.load(open(tpath)).get(keyname[dom])
             if tj:
@@ -321,7 +395,7 @@ def main():
                            "ratio": round((tj["fetch_bytes"] + tj["write_bytes"]) / tj["algorithmic_bytes"], 3), "shape": tj["shape"]}
                 tnote = tj.get("note", "")
         roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsource if traffic else None, "traffic_note": tnote,
                 "launches": n, "sampled_every": gt.stride,
                 "class_launches_in_timed_region": gt.per_mode.get(dom, 0), "avg_launch_us": round(secs / n * 1e6, 1),
                 "flops_per_launch": round(fl / n / 1e9, 2), "flops_per_launch_unit": "GFLOP",
@@ -333,7 +407,16 @@ def main():
     # harness that wants every video on rank 0.  Run it once here, untimed (not part of `value`), with a tensor of the decoded
     # size (24x320x576x3 = 13.3 MB per rank) derived from this rank's latents, so the N > 1 runs really cross xGMI.
     gather_ms = None
+    rccl_seen = None
     if dist is not None:
+        # proof that the collective backend saw N distinct devices: all_gather of (rank, device ordinal, device UUID hash)
+        props = torch.cuda.get_device_properties(dev)
+        uid = abs(hash(str(getattr(props, "uuid", "")) + str(local))) % (1 << 31)
+        mine = torch.tensor([rank, local, uid], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rccl_seen = {"world_size": dist.get_world_size(), "ranks": sorted(int(t[0]) for t in allr),
+                     "distinct_devices": len({(int(t[1]), int(t[2])) for t in allr}), "backend": backend}
         from lvd_amd.sharding import gather_frames
         vid = (latents[0, :3].permute(1, 2, 3, 0).clamp(-1, 1).add(1).mul(127.5)).to(torch.uint8)             # (F, h, w, 3)
         vid = vid.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()                                 # (F, 320, 576, 3)
@@ -351,12 +434,14 @@ def main():
         cpu = cpu_baseline(sd_cpu, cfg)
 
     if rank == 0:
-        value = world * FRAMES / (ms_guided * 1e-3)
+        value = world * V * FRAMES / (ms_guided * 1e-3)
         tf_cfg = 52.88 if args.gligen else TF_CFG_FWD  # CFG forward with the fusers enabled
-        step_tf = tf_cfg + TF_GUIDANCE_ITER
+        step_tf = V * (tf_cfg + TF_GUIDANCE_ITER)
+        tf_cfg = V * tf_cfg
         mean40 = (10 * ms_guided + 30 * ms_unguided) / 40
         out = {
-            "metric": "denoise-step frames/sec, LVD-Zeroscope 576x320x24 w/ guidance" + (" + GLIGEN adapters" if args.gligen else ""),
+            "metric": "denoise-step frames/sec, LVD-Zeroscope 576x320x24 w/ guidance" + (" + GLIGEN adapters" if args.gligen else "")
+                      + (f" (THROUGHPUT MODE, not the headline: {V} videos per GPU, CFG batch {2 * V})" if V > 1 else ""),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_guided, 2), "ms_per_step_stat": "median of the K per-step times (HIP events on the launch stream)",
             "mean_ms_per_step": round(ms_mean, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -364,15 +449,17 @@ def main():
             "config": {"workload": "lvd_zeroscope 576x320x24 (latent 40x72, 24 frames), guided step: 1 guidance iteration over 6 keys "
                                    "+ CFG UNet forward (B=2) + DPM-Solver++ update; random-init zeroscope-topology weights (1411M params)"
                                    + (", gated topology (1624M params) with the GLIGEN fusers enabled" if args.gligen else ""),
-                       "videos_per_gpu": 1, "parallelism": f"dp{world} (independent samples, no data-path collective)",
+                       "videos_per_gpu": V, "parallelism": f"dp{world} (independent samples, no data-path collective)",
                        "guidance_scale": 9.0, "objects": 3},
             "unguided_ms_per_step": round(ms_unguided, 2),
-            "unguided_frames_per_s": round(world * FRAMES / (ms_unguided * 1e-3), 2),
-            "schedule40_mean_frames_per_s": round(world * FRAMES / (mean40 * 1e-3), 2),
+            "unguided_frames_per_s": round(world * V * FRAMES / (ms_unguided * 1e-3), 2),
+            "schedule40_mean_frames_per_s": round(world * V * FRAMES / (mean40 * 1e-3), 2),
             "step_algorithmic_tflop": step_tf,
             "step_mfma_frac": round(step_tf / (ms_guided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "unguided_mfma_frac": round(tf_cfg / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "loss_finite": finite,
+            "guided_step_is": "guidance.hip_latent_backward_guidance (one iteration; with max_iter = 1 its loss stays on the device until the next step reads it) + CFG forward + fused CFG/DPM update",
+            "gemm_autotune_table": table_loaded, "rccl_ranks_seen": rccl_seen,
             "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -41,7 +41,9 @@ def build_parser():
     p.add_argument("--template_version", choices=["v0.1"], required=True)
     p.add_argument("--dry-run", action="store_true", help="skip the generation")
     p.add_argument("--gemm_autotune_table", default=None, help="JSON of per-shape GEMM tile-geometry choices: loaded if it exists (every rank / run "
-                   "then uses the same summation order: bit-identical videos for the same prompt and seed), written by rank 0 otherwise")
+                   "then uses the same summation order: bit-identical videos for the same prompt and seed), written at the end otherwise (the union "
+                   "of all ranks' choices).  Default: the table shipped for the zeroscope 576x320x24 topology, profiles/gemm_autotune_576x320x24.json; "
+                   "shapes a table does not hold are tuned on first use")
     for a in ["fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "loss_threshold", "loss_scale", "boxdiff_loss_scale", "com_loss_scale",
               "gligen_scheduled_sampling_beta"]:
         p.add_argument("--" + a, default=None, type=float)
@@ -74,9 +76,14 @@ def main(argv=None):
         if world > 1:
             import torch.distributed as dist
             dist.init_process_group(os.environ.get("LVD_DIST_BACKEND", "nccl"))  # RCCL; only the end-of-run tally uses it
-        if args.gemm_autotune_table and os.path.exists(args.gemm_autotune_table):
-            from lvd_amd import ops
-            ops.load_gemm_autotune_table(args.gemm_autotune_table)  # same tile geometry per shape in every rank / run
+        from lvd_amd import ops
+        shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gemm_autotune_576x320x24.json")
+        table_path = args.gemm_autotune_table or (shipped if os.path.exists(shipped) else None)
+        if table_path and os.path.exists(table_path):
+            ops.load_gemm_autotune_table(table_path)  # same tile geometry per shape in every rank / run
+        elif world > 1:
+            print(f"rank {rank}: no GEMM autotune table: every rank times the tile geometries itself, so this sharded run is NOT bit-reproducible "
+                  "against a single-process run (pass --gemm_autotune_table: the merged table is written at the end and pins later runs)")
         if args.synthetic_weights:
             _common.configure(state_dict="synthetic")
         elif args.checkpoint and os.path.isdir(args.checkpoint):
@@ -122,61 +129,77 @@ def main(argv=None):
     print(f"Save dir: {save_dir}  (rank {rank}/{world})")
 
     ind, generated = 0, 0
-    for regenerate_ind in range(args.regenerate):
-        if cache:
-            cache.reset_access()
-        for prompt_ind, prompt in enumerate(prompts):
-            if prompt_ind < args.skip_first_prompts or (args.num_prompts is not None and prompt_ind >= args.skip_first_prompts + args.num_prompts):
-                ind += 1  # outside the requested range: the cache entry is NOT consumed (reference generate.py:255-262)
-                continue
-            prompt = prompt.strip().rstrip(".")
-            resp = None if baseline else cache.get(prompt)  # every rank walks the cache identically (sequential semantics)
-            if not sharding.owns(ind, rank, world):
+    failure = None
+    try:
+        for regenerate_ind in range(args.regenerate):
+            if cache:
+                cache.reset_access()
+            for prompt_ind, prompt in enumerate(prompts):
+                if prompt_ind < args.skip_first_prompts or (args.num_prompts is not None and prompt_ind >= args.skip_first_prompts + args.num_prompts):
+                    ind += 1  # outside the requested range: the cache entry is NOT consumed (reference generate.py:255-262)
+                    continue
+                prompt = prompt.strip().rstrip(".")
+                resp = None if baseline else cache.get(prompt)  # every rank walks the cache identically (sequential semantics)
+                if not sharding.owns(ind, rank, world):
+                    ind += 1
+                    continue
+                if not baseline and resp is None:
+                    print(f"Cache miss, skipping prompt: {prompt}")
+                    ind += 1
+                    continue
+                img_dir = f"{save_dir}/{ind}"
+                done = os.path.exists(img_dir) and len([f for f in os.listdir(img_dir) if f.endswith("joblib")]) >= args.repeats
+                if done:
+                    print(f"Image exists at {img_dir}, skipping")
+                    ind += 1
+                    continue
+                os.makedirs(img_dir, exist_ok=True)
+                try:
+                    layout = {"Prompt": prompt, "Background keyword": "", **{f"Frame {k + 1}": [] for k in range(6)}} if baseline else dsl.parse_layout_response(prompt, resp)
+                    print("parsed_layout:", layout)
+                    if not args.dry_run:
+                        from lvd_amd.generation import _common
+                        _common.configure(img_dir=img_dir)
+                        for repeat_ind in range(args.repeats):
+                            run(layout, seed=ind + repeat_ind * 6789 + args.seed_offset, repeat_ind=repeat_ind, **run_kwargs)
+                            generated += 1
+                except KeyboardInterrupt:
+                    raise SystemExit(1)
+                except RuntimeError:
+                    print("***RuntimeError: might run out of memory, skipping the current one***")
+                    print(traceback.format_exc())
+                    time.sleep(1)
+                except Exception as e:  # noqa: BLE001
+                    print(f"***Error: {e}***")
+                    print(traceback.format_exc())
+                    if args.no_continue_on_error:
+                        raise
                 ind += 1
-                continue
-            if not baseline and resp is None:
-                print(f"Cache miss, skipping prompt: {prompt}")
-                ind += 1
-                continue
-            img_dir = f"{save_dir}/{ind}"
-            done = os.path.exists(img_dir) and len([f for f in os.listdir(img_dir) if f.endswith("joblib")]) >= args.repeats
-            if done:
-                print(f"Image exists at {img_dir}, skipping")
-                ind += 1
-                continue
-            os.makedirs(img_dir, exist_ok=True)
-            try:
-                layout = {"Prompt": prompt, "Background keyword": "", **{f"Frame {k + 1}": [] for k in range(6)}} if baseline else dsl.parse_layout_response(prompt, resp)
-                print("parsed_layout:", layout)
-                if not args.dry_run:
-                    from lvd_amd.generation import _common
-                    _common.configure(img_dir=img_dir)
-                    for repeat_ind in range(args.repeats):
-                        run(layout, seed=ind + repeat_ind * 6789 + args.seed_offset, repeat_ind=repeat_ind, **run_kwargs)
-                        generated += 1
-            except KeyboardInterrupt:
-                raise SystemExit(1)
-            except RuntimeError:
-                print("***RuntimeError: might run out of memory, skipping the current one***")
-                print(traceback.format_exc())
-                time.sleep(1)
-            except Exception as e:  # noqa: BLE001
-                print(f"***Error: {e}***")
-                print(traceback.format_exc())
-                if args.no_continue_on_error:
-                    raise
-            ind += 1
+    except BaseException as e:  # noqa: BLE001 — a rank that dies here must still meet the others in the tally below, or they hang in it
+        failure = e
+        print(f"rank {rank}: stopping after {generated} video(s): {type(e).__name__}: {e}")
     print(f"rank {rank}: generated {generated} video(s)")
-    if not args.dry_run and args.gemm_autotune_table and rank == 0 and not os.path.exists(args.gemm_autotune_table):
+    if not args.dry_run and args.gemm_autotune_table and not os.path.exists(args.gemm_autotune_table):
         from lvd_amd import ops
-        ops.save_gemm_autotune_table(args.gemm_autotune_table)
+        if dist is not None:  # the union of what the ranks tuned (rank 0's choice wins where two ranks timed the same shape)
+            tabs = [None] * world
+            dist.all_gather_object(tabs, [[list(k), v] for k, v in ops.gemm_autotune_table().items()])
+            if rank == 0:
+                for tab in reversed(tabs):
+                    for k, v in tab:
+                        k[7] = tuple(k[7]) if k[7] is not None else None
+                        ops._gemm_choice[tuple(k)] = int(v)
+        if rank == 0:
+            ops.save_gemm_autotune_table(args.gemm_autotune_table)
     if dist is not None:  # end-of-run tally over RCCL (the only collective: every rank wrote its own directory entries)
         import torch
-        tot = torch.tensor([generated], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        tot = torch.tensor([generated, int(failure is not None)], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tot)
         if rank == 0:
-            print(f"all ranks: generated {int(tot.item())} video(s)")
+            print(f"all ranks: generated {int(tot[0].item())} video(s)" + (f", {int(tot[1].item())} rank(s) stopped on an error" if int(tot[1].item()) else ""))
         dist.destroy_process_group()
+    if failure is not None:
+        raise failure
     return generated
 
 

@@ -240,7 +240,12 @@ def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes
     loss_kw = {k: kwargs[k] for k in _LOSS_OPTIONS if k in kwargs}
     text = cond_embeddings if hasattr(cond_embeddings, "kv") else engine.encode_text(cond_embeddings)
     iteration = 0
-    loss_val = float(loss)
+    host = getattr(loss, "_host_copy", None)  # a loss this function returned earlier: its value is already in pinned host memory
+    if host is not None:
+        host[1].synchronize()
+        loss_val = float(host[0])
+    else:
+        loss_val = float(loss)
     if index < max_index_step:
         if isinstance(max_iter, list):
             max_iter = max_iter[index]
@@ -266,13 +271,25 @@ def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes
                 warnings.warn("No scaling in guidance is performed")
                 scale = 1.0
             latents = ops.axpy_(latents.to(torch.float32).contiguous().clone(), grad, scale)
-            loss_val = float(loss_t.item())  # one host sync per iteration, as the reference's loss.item()
-            if math.isnan(loss_val):
-                print("**Loss is NaN**")
             loss = loss_t
             iteration += 1
-            if verbose:
-                print(f"time index {index}, loss: {loss_val / loss_scale:.3f}, loss threshold: {loss_threshold:.3f}, iteration: {iteration}")
+            # The reference reads loss.item() after every iteration (models/pipelines.py:134).  The value is needed on the host only to
+            # decide whether ANOTHER iteration follows (or to print it).  When this was the last iteration the device tensor is handed
+            # back with an asynchronous pinned-memory copy attached (`_host_copy`: the copy sits on the stream right behind the loss
+            # reduction, i.e. in front of nothing the caller still queues); the entry check of the next guided step reads that copy
+            # after its event — same control flow, no pipeline stall between the backward and the CFG forward.
+            if not (iteration < max_iter or verbose):
+                pinned = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                pinned.copy_(loss_t.reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                loss_t._host_copy = (pinned, ev)
+            if iteration < max_iter or verbose:
+                loss_val = float(loss_t.item())
+                if math.isnan(loss_val):
+                    print("**Loss is NaN**")
+                if verbose:
+                    print(f"time index {index}, loss: {loss_val / loss_scale:.3f}, loss threshold: {loss_threshold:.3f}, iteration: {iteration}")
     if return_saved_attn:
         return latents, loss, saved_attn_to_return
     return latents, loss

@@ -178,7 +178,8 @@ print("GENERATED", n, flush=True)
 def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
     """generate.py under torch.distributed.run, two ranks (both on this one GPU, gloo for the end-of-run tally): every rank binds a
     device, takes the prompts `sharding.owns` gives it, and — with the GEMM autotune table of the single-process run loaded — writes
-    bit-identical videos (global prompt index -> seed, same tile geometry per shape in every process)."""
+    bit-identical videos (global prompt index -> seed, same tile geometry per shape in every process).  Three runs: the single-process run
+    that tunes and writes the table, a single-process run that loads it ("pinned"), and the two-rank run that loads it."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -207,13 +208,21 @@ def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
     one = subprocess.run([sys.executable, str(driver)] + argv("one"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert one.returncode == 0 and "GENERATED 4" in one.stdout, one.stdout[-2000:] + one.stderr[-2000:]
     assert table.exists()
-    port = 29600 + os.getpid() % 300
+    pinned = subprocess.run([sys.executable, str(driver)] + argv("pinned"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert pinned.returncode == 0 and "GENERATED 4" in pinned.stdout, pinned.stdout[-2000:] + pinned.stderr[-2000:]
+    import socket
+    with socket.socket() as sk:  # a port nothing else on this box holds
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), str(driver)] + argv("two"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     assert two.stdout.count("GENERATED 2") == 2, two.stdout[-2000:]  # two prompts per rank
     root = "imgs_shardtest_templatev0.1_lvd_zeroscope/run0"
+    vids = {k: [joblib.load(tmp_path / k / root / str(i) / "video_0.joblib") for i in range(4)] for k in ("one", "pinned", "two")}
+    report = [(i, np.array_equal(vids["one"][i], vids["pinned"][i]), np.array_equal(vids["two"][i], vids["pinned"][i])) for i in range(4)]
+    print("prompt: (tuning run == pinned run, two ranks == pinned run):", report)
     for i in range(4):
-        a = joblib.load(tmp_path / "one" / root / str(i) / "video_0.joblib")
-        b = joblib.load(tmp_path / "two" / root / str(i) / "video_0.joblib")
-        assert a.shape == (24, 320, 576, 3) and np.array_equal(a, b), f"prompt {i} differs between the sharded and the single-process run"
+        assert vids["pinned"][i].shape == (24, 320, 576, 3)
+        assert report[i][2], f"prompt {i} differs between the sharded run and the single-process run on the same table: {report}"
+        assert report[i][1], f"prompt {i} differs between the run that tuned the table and a run that loaded it: {report}"
