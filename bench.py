@@ -410,8 +410,10 @@ def main():
     rccl_seen = None
     if dist is not None:
         # proof that the collective backend saw N distinct devices: all_gather of (rank, device ordinal, device UUID hash)
+        import zlib
         props = torch.cuda.get_device_properties(dev)
-        uid = abs(hash(str(getattr(props, "uuid", "")) + str(local))) % (1 << 31)
+        ident = "|".join(str(getattr(props, k, "")) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
+        uid = zlib.crc32(ident.encode())  # stable across processes (str hashes are salted per process): same GPU -> same id
         mine = torch.tensor([rank, local, uid], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
