@@ -360,6 +360,9 @@ __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_para
 }
 
 // ------------------------------------------------------------------------------------ 3. dQ
+// NT = compile-time bound on the object tokens of the launch (2 / 4 / 8 / 16): the per-score test "is this key one of the object tokens"
+// costs 16 x NT selects per key tile, and with the bound fixed at 16 it was the kernel (768 VALU operations per tile against 8 MFMAs).
+template <int NT>
 __global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
   __shared__ uint32_t kt_lds[64 * TP];
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -374,19 +377,23 @@ __global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
   const long row = ((long)f * p.heads + h);
   const float lse2 = p.lse[row * p.P + qic] * 1.4426950408889634f;
   const float sc = p.scale * 1.4426950408889634f;
-  // per-query token-column gradients and c = sum_t A_t dA_t
-  float da[MAXTOK];
-  int tk[MAXTOK];
+  // per-query token-column gradients and c = sum_t A_t dA_t; every load is issued unconditionally (clamped token index, masked
+  // value): a load inside a branch is waited for inside that branch, one memory round trip per token
+  float da[NT], pa[NT];
+  int tk[NT];
   float cq = 0.f;
 #pragma unroll
-  for (int t = 0; t < MAXTOK; ++t) {
-    da[t] = 0.f; tk[t] = -1;
-    if (t < p.ntok) {
-      long idx = (row * p.ntok + t) * p.P + qic;
-      da[t] = p.dprobs[idx];
-      tk[t] = p.tok_ids[t];
-      cq += p.probs[idx] * da[t];
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int tt = min(t, p.ntok - 1);
+    const long idx = (row * p.ntok + tt) * p.P + qic;
+    da[t] = p.dprobs[idx];
+    pa[t] = p.probs[idx];
+    tk[t] = p.tok_ids[tt];
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t >= p.ntok) { da[t] = 0.f; tk[t] = -1; }
+    cq += pa[t] * da[t];
   }
   f32x16 dq0, dq1;
 #pragma unroll
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
       float pr = kidx < p.ntext ? fast_exp2(st[e] * sc - lse2) : 0.f;
       float g = -cq;
 #pragma unroll
-      for (int t = 0; t < MAXTOK; ++t) g += (tk[t] == kidx) ? da[t] : 0.f;
+      for (int t = 0; t < NT; ++t) g += (tk[t] == kidx) ? da[t] : 0.f;
       ds[e] = pr * g;
     }
 #pragma unroll
@@ -487,7 +494,10 @@ extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) {
   LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_dq: ntok=%d outside 1..%d", p->ntok, MAXTOK);
   LVD_CHECK(p->acc_mode >= 0 && p->acc_mode <= 3 && (p->acc_mode == 0 || (p->acc32 && p->ldacc % 4 == 0)), "ca_dq: acc_mode %d needs an fp32 accumulator", p->acc_mode);
   dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
-  hipLaunchKernelGGL(ca_dq_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  if (p->ntok <= 2) hipLaunchKernelGGL(ca_dq_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  else if (p->ntok <= 4) hipLaunchKernelGGL(ca_dq_kernel<4>, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  else if (p->ntok <= 8) hipLaunchKernelGGL(ca_dq_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, *p);
+  else hipLaunchKernelGGL(ca_dq_kernel<MAXTOK>, grid, dim3(64), 0, (hipStream_t)stream, *p);
   LVD_LAUNCH_CHECK();
   return 0;
 }
