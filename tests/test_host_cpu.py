@@ -42,6 +42,29 @@ def test_struct_sizes_match_header():
     assert sizes == [ctypes.sizeof(m) for m in mirrors]
 
 
+def test_shipped_gemm_autotune_table_is_loadable():
+    """profiles/gemm_autotune_576x320x24.json (loaded by default by bench.py / generate.py) has the key layout `ops.gemm` looks up and
+    only names tile geometries the library knows."""
+    from lvd_amd import ops
+    path = os.path.join(ROOT, "profiles", "gemm_autotune_576x320x24.json")
+    assert os.path.exists(path)
+    saved = dict(ops._gemm_choice)
+    try:
+        ops._gemm_choice.clear()
+        ops.load_gemm_autotune_table(path)
+        tab = ops.gemm_autotune_table()
+        assert len(tab) >= 150
+        known = set(ops.GEMM_CANDIDATES) | {ops.SPLITK_VARIANT, ops.SPLITK_WIDE_VARIANT} | set(ops.TAIL_VARIANTS) | set(ops.HALO_VARIANTS)
+        for k, v in tab.items():
+            assert len(k) == 14 and v in known, (k, v)
+            assert k[0] in (ops.A_PLAIN, ops.A_CONV3X3, ops.A_TCONV3, ops.A_CONV3X3_T2) and (k[7] is None or len(k[7]) == 4)
+        # the headline shapes are in it: level-0 QKV projection of the CFG batch and the level-0 resnet conv
+        assert any(k[:4] == (ops.A_PLAIN, 138240, 960, 320) for k in tab) and any(k[:4] == (ops.A_CONV3X3, 138240, 320, 2880) for k in tab)
+    finally:
+        ops._gemm_choice.clear()
+        ops._gemm_choice.update(saved)
+
+
 def test_unet_constructor_and_loading_errors_match_reference_behaviour():
     with pytest.raises(NotImplementedError):
         UNet3DConditionModel(num_attention_heads=8)

@@ -547,3 +547,35 @@ def test_gemm_split_k(SPLITK):
     reft = F.conv3d(x5, wtc[..., None, None], None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(Bt * Fr * hw, c)
     out = ops.gemm(xt, bf(wtc.permute(0, 2, 1).reshape(c, 3 * c).contiguous()), mode=ops.A_TCONV3, frames=Fr, hw=hw, variant=SPLITK)
     close(out, reft, 6e-3, f"v{SPLITK} split-K tconv")
+
+
+def test_gemm_bit_reproducible_next_to_a_cotenant_process():
+    """Regression test of the round-3 race: the first 64-deep ring refilled an LDS slot that sibling waves of the same group were still
+    reading.  Alone on the GPU the refill always landed after those reads and every test passed; next to a SECOND PROCESS whose small
+    workgroups share the CUs (other launch timing, other workgroup placement) 8-25 of 25 launches came out with up to 4 000 wrong elements.
+    Every hand-synchronised GEMM variant must give the same bits on every launch while such a co-tenant runs."""
+    import os
+    import subprocess
+    import sys
+    import time
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "gemm_cotenant_probe.py")
+    load = subprocess.Popen([sys.executable, probe, "load", "60"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        time.sleep(8)  # the co-tenant has built its tensors and loops over GroupNorm / LayerNorm / small GEMM / SiLU launches
+        assert load.poll() is None, "the co-tenant process died"
+        M, N, K = 69120, 1536, 512
+        a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
+        bias = rnd(N, seed=3)
+        for v in (11, 111, 131, 211, 231, 225):
+            ref = ops.gemm(a, w, bias=bias, variant=v)
+            for rep in range(12):
+                assert torch.equal(ops.gemm(a, w, bias=bias, variant=v), ref), f"variant {v}: launch {rep} differs from the first one"
+        n, c, h, wd = 48, 64, 40, 72
+        x, wt = bf(to_tokens(rnd(n, c, h, wd, seed=4))), pack_conv(rnd(64, c, 3, 3, seed=5, scale=0.05))
+        for v in (41, 45, 47):
+            ref = ops.gemm(x, wt, mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=v)
+            for rep in range(8):
+                assert torch.equal(ops.gemm(x, wt, mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=v), ref), f"conv variant {v}: launch {rep} differs"
+    finally:
+        load.terminate()
+        load.wait(timeout=30)
