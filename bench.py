@@ -385,9 +385,9 @@ def main():
         dom = max(agg, key=lambda m: agg[m][1])
         n, secs, fl = agg[dom]
         ach = fl / secs / 1e12
-        traffic, tnote = None, "no profiles/r02_gemm_traffic.json next to bench.py"
-        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
-        tsource = "profiles/r02_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes of tools/gemm_pmc.py; NOT measured in this run)"
+        traffic, tnote = None, "no profiles/r03_gemm_traffic.json next to bench.py"
+        tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+        tsource = "profiles/r03_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes: tools/traffic_passes.sh; NOT measured in this run)"
         if os.path.exists(tpath):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py, rolled up by tools/pmc_traffic.py
             tj = json.load(open(tpath)).get(keyname[dom])
             if tj:
