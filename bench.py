@@ -217,6 +217,18 @@ def main():
                     "their CFG forwards batched (B = 2V); guidance stays one recorded pass per sample")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run on this node (rendezvous on
+        # 127.0.0.1; the container hostname may not resolve).  Rank 0 of the children prints the one JSON line; the exit code is theirs.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -273,7 +285,7 @@ def main():
     sampler.reset(latents)
     hp = dict(loss_scale=2.5, fg_top_p=0.25, bg_top_p=0.25, fg_weight=1.0, bg_weight=2.0)  # README.md:68 weak guidance
 
-    state = {"i": 0}
+    state = {"i": 0, "loss": 10000.0, "loss_more": [10000.0] * (V - 1)}
 
     gkw = dict(loss_scale=hp["loss_scale"], loss_threshold=0.0, max_iter=1, max_index_step=10, guidance_attn_keys=GUIDANCE_KEYS,
                **{k: v for k, v in hp.items() if k != "loss_scale"})
@@ -296,11 +308,15 @@ def main():
         i = state["i"] % 10  # guidance is active for step indices < max_index_step=10
         sched.step_index, sched.lower_order_nums = i, min(i, 2)
         t = int(sched.timesteps[i])
-        new, loss = guidance.hip_latent_backward_guidance(sched, engine, text_cond, i, bboxes, positions, t, latents, 10000.0, **gkw)
+        # the carried loss is the tensor the previous guided step returned (controllable_pipeline_text_to_video_synth.py keeps `loss` across
+        # steps): its entry check waits for the pinned-memory copy queued behind the previous backward, so that wait is inside the timed region
+        new, loss = guidance.hip_latent_backward_guidance(sched, engine, text_cond, i, bboxes, positions, t, latents, state["loss"], **gkw)
         latents.copy_(new)
-        for (l, _), tc in zip(more, text_cond_more if V > 1 else []):
-            nl, _ = guidance.hip_latent_backward_guidance(sched, engine, tc, i, bboxes, positions, t, l, 10000.0, **gkw)
+        state["loss"] = loss
+        for v, ((l, _), tc) in enumerate(zip(more, text_cond_more if V > 1 else [])):
+            nl, lv = guidance.hip_latent_backward_guidance(sched, engine, tc, i, bboxes, positions, t, l, state["loss_more"][v], **gkw)
             l.copy_(nl)
+            state["loss_more"][v] = lv
         if V > 1:
             cfg_all(i)
         else:
@@ -325,11 +341,16 @@ def main():
 
     def keep_finite():
         # random-init weights are not a denoiser: re-draw the latents so timing never runs on inf/nan (untimed)
-        for l in [latents] + [m for m, _ in more]:
-            if not bool(torch.isfinite(l).all()) or float(l.abs().max()) > 50:
+        for v, l in enumerate([latents] + [m for m, _ in more]):
+            xp = sampler.x0_prev if v == 0 else x0_prev_more[v - 1]
+            if not bool(torch.isfinite(l).all()) or float(l.abs().max()) > 50 or not bool(torch.isfinite(xp).all()):
                 l.copy_(torch.randn(l.shape, device=dev, generator=g))
-        if not bool(torch.isfinite(sampler.x0_prev).all()):
-            sampler.reset(latents)
+                if v == 0:
+                    sampler.reset(latents)      # a re-drawn sample starts a fresh multistep history
+                    state["loss"] = 10000.0
+                else:
+                    xp.zero_()
+                    state["loss_more"][v - 1] = 10000.0
 
     guided_step()  # untimed preparation, independent of --warmup: shapes the autotune table does not hold are tuned on first use
     unguided_step()
@@ -460,7 +481,7 @@ def main():
             "step_mfma_frac": round(step_tf / (ms_guided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "unguided_mfma_frac": round(tf_cfg / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "loss_finite": finite,
-            "guided_step_is": "guidance.hip_latent_backward_guidance (one iteration; with max_iter = 1 its loss stays on the device until the next step reads it) + CFG forward + fused CFG/DPM update",
+            "guided_step_is": "guidance.hip_latent_backward_guidance (one iteration; the returned loss tensor is carried into the next step, whose entry check waits for its pinned host copy) + CFG forward + fused CFG/DPM update",
             "gemm_autotune_table": table_loaded, "rccl_ranks_seen": rccl_seen,
             "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,

@@ -122,9 +122,21 @@ def main(argv=None):
     if args.force_run_ind is not None:
         run_ind = args.force_run_ind
     else:
+        # Reference generate.py:225-234 probes for the first free run directory.  Under N ranks only rank 0 probes and the others take its
+        # answer: a rank that finishes importing late would otherwise see the run0/ its peers have already created and write to run1/.
         run_ind = 0
-        while os.path.exists(f"{base_save}/run{run_ind}"):
-            run_ind += 1
+        if rank == 0:
+            while os.path.exists(f"{base_save}/run{run_ind}"):
+                run_ind += 1
+        if world > 1:
+            if dist is None:  # --dry-run never touched torch: a gloo group just for this broadcast and the barrier below
+                import torch.distributed as dist
+                dist.init_process_group("gloo")
+            box = [run_ind]
+            dist.broadcast_object_list(box, src=0)
+            run_ind = int(box[0])
+            if rank == 0:
+                os.makedirs(f"{base_save}/run{run_ind}", exist_ok=True)  # claimed before any rank starts writing
     save_dir = f"{base_save}/run{run_ind}"
     print(f"Save dir: {save_dir}  (rank {rank}/{world})")
 

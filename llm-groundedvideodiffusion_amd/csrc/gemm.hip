@@ -435,6 +435,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   }();
   int v = p->variant ? p->variant : variant;
   int rc;
+  LVD_CHECK(v >= 0 && v < 300, "gemm: variant %d names no tile geometry", v);  // before the tail / non-tail split: 331, 431, ... must not reach run_with_tail
   const int vb = v % 100;  // + LVD_GEMM_V_ADMA / ADMA64 select the main-loop generation of the same geometry
   if (vb == LVD_GEMM_V_RING256W_TAIL || vb == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
   else rc = run_variant(p, stream, v);

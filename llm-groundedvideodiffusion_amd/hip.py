@@ -178,6 +178,9 @@ SYMBOLS = {
 }
 
 _lib = None
+# The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
+# added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
+ABI_VERSION = 101
 
 
 def lib():
@@ -201,6 +204,10 @@ def lib():
             else:
                 fn.restype = C.c_int
                 fn.argtypes = argtypes
+        got = l.lvdhip_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports lvdhip_version() = {got}, the Python side was written for {ABI_VERSION}: rebuild the library "
+                               "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = l
     return _lib
 

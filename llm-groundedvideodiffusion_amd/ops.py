@@ -168,6 +168,8 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     _chk_f32(bias)
     _chk_f32_rows(rowbias)  # may be a column range of a wider matrix (engine: all temb projections of a forward are one product)
     N, K = w.shape if (n is None or k is None) else (n, k)
+    if rowbias is not None:  # the kernels read it with 16-byte loads at rowbias + sample * stride + n
+        assert rowbias.data_ptr() % 16 == 0 and rowbias.stride(0) % 4 == 0 and rowbias.shape[1] == N, "rowbias: 16-byte aligned rows of N floats expected"
     assert w.is_contiguous()
     c1 = a1.shape[1]
     c2 = a2.shape[1] if a2 is not None else 0
@@ -182,6 +184,7 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     if out is None:
         out = torch.empty((m, n_out), dtype=torch.float32 if out_fp32 else torch.bfloat16, device=a1.device)
     assert out.shape[0] == m and out.shape[1] >= n_out
+    assert rowbias is None or (rows_per_sample > 0 and rowbias.shape[0] * rows_per_sample >= m), "rowbias: one row per sample of rows_per_sample token rows"
     p = hip.GemmParams()
     p.a1, p.a2, p.w, p.bias, p.rowbias, p.res, p.out = _p(a1), _p(a2), _p(w), _p(bias), _p(rowbias), _p(res), _p(out)
     p.M, p.N, p.K = m, N, K

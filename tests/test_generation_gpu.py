@@ -196,11 +196,11 @@ def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
     driver.write_text(_DRIVER.format(repo=repo, small=SMALL))
     table = tmp_path / "gemm_table.json"
 
-    def argv(out):
+    def argv(out, pin_run=True):
         return ["--model", "gpt-4", "--run-model", "lvd_zeroscope", "--prompt-type", "shardtest", "--prompts-file", str(tmp_path / "prompts.txt"),
                 "--template_version", "v0.1", "--num_frames", "24", "--num_inference_steps", "3", "--max_index_step", "1", "--max_iter", "1",
-                "--repeats", "1", "--force_run_ind", "0", "--cache-dir", str(cache_dir), "--img-root", str(tmp_path / out),
-                "--gemm_autotune_table", str(table)]
+                "--repeats", "1", "--cache-dir", str(cache_dir), "--img-root", str(tmp_path / out),
+                "--gemm_autotune_table", str(table)] + (["--force_run_ind", "0"] if pin_run else [])
 
     env = dict(os.environ, LVD_DIST_BACKEND="gloo", PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -215,10 +215,12 @@ def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(driver)] + argv("two"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+                          "--master-port", str(port), str(driver)] + argv("two", pin_run=False), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     assert two.stdout.count("GENERATED 2") == 2, two.stdout[-2000:]  # two prompts per rank
     root = "imgs_shardtest_templatev0.1_lvd_zeroscope/run0"
+    # no --force_run_ind in the sharded run: rank 0 picks the run directory and broadcasts it, so there is exactly one
+    assert sorted(os.listdir(tmp_path / "two" / "imgs_shardtest_templatev0.1_lvd_zeroscope")) == ["run0"]
     vids = {k: [joblib.load(tmp_path / k / root / str(i) / "video_0.joblib") for i in range(4)] for k in ("one", "pinned", "two")}
     report = [(i, np.array_equal(vids["one"][i], vids["pinned"][i]), np.array_equal(vids["two"][i], vids["pinned"][i])) for i in range(4)]
     print("prompt: (tuning run == pinned run, two ranks == pinned run):", report)

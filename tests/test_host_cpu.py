@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().lvdhip_version() >= 100
+    assert hip.lib().lvdhip_version() == hip.ABI_VERSION  # lib() itself refuses a library of another ABI version
 
 
 def test_struct_sizes_match_header():
@@ -212,6 +212,35 @@ def _shard_worker(rank, world, q):
     assert [float(f[0, 0]) for f in allf] == [0.0, 1.0]
     q.put(jobs)
     dist.destroy_process_group()
+
+
+def test_two_rank_generate_agrees_on_one_run_directory(tmp_path):
+    """generate.py under torch.distributed.run (two ranks, gloo, --dry-run: no GPU): without --force_run_ind the run directory is
+    chosen by rank 0 and broadcast, so a rank that arrives late (here: rank 1 sleeps before main) does not see the run0/ its peer has
+    created and move on to run1/ (reference generate.py:225-234 probes per process; it is single-process)."""
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = tmp_path / "driver.py"
+    driver.write_text("import os, sys, time\nsys.path.insert(0, %r)\nimport generate\n"
+                      "time.sleep(3.0 if os.environ.get('RANK') == '1' else 0.0)\ngenerate.main(sys.argv[1:])\n" % repo)
+    (tmp_path / "prompts.txt").write_text("a cat walking\na dog running\na bird flying\na fish swimming\n")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for attempt in range(2):  # the second launch must take run1/ on both ranks
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), str(driver), "--model", "gpt-4", "--run-model", "zeroscope", "--prompt-type", "plain",
+                            "--prompts-file", str(tmp_path / "prompts.txt"), "--template_version", "v0.1", "--dry-run", "--img-root", str(tmp_path / "out")],
+                           env=env, capture_output=True, text=True, timeout=300, cwd=repo)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        base = tmp_path / "out" / "imgs_plain_templatev0.1_zeroscope"
+        assert sorted(os.listdir(base)) == [f"run{i}" for i in range(attempt + 1)], (os.listdir(base), r.stdout[-1500:])
+        assert sorted(os.listdir(base / f"run{attempt}")) == ["0", "1", "2", "3"]  # both ranks wrote their prompt directories into the same run
 
 
 def test_gemm_workspace_query_needs_no_gpu():
