@@ -124,8 +124,9 @@ int lvdhip_gemm_workspace_bytes(const lvd_gemm_params* p, int64_t* bytes);
  *       rows_per_sample = H*W (statistics per frame)
  *   5-D GroupNorm  (TransformerTemporalModel.norm models/transformer_temporal.py:148-153,
  *       TemporalConvLayer norms): rows_per_sample = F*H*W (statistics across frames)
- * stats: partial per-channel sums -> finalize to per (sample, channel) scale/shift:
- *   y = silu?( x * scale[s,c] + shift[s,c] )
+ * stats: per-(row chunk, group) partial sums (one launch); apply: every workgroup folds the chunk partials of its sample in a
+ *   fixed order (a few KB from L2), forms scale = rstd*gamma, shift = beta - mean*rstd*gamma in registers and writes
+ *   y = silu?( x * scale + shift ); the first workgroup of a sample also writes (mean, rstd) for the backward.  No finalize launch.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const lvd_bf16* x1; const lvd_bf16* x2;   /* channel concat of two sources (x2 may be NULL) */
@@ -133,10 +134,10 @@ typedef struct {
   int32_t rows, rows_per_sample, groups;
   float eps;
   const float* gamma; const float* beta;    /* [c] */
-  float* partial;      /* workspace: [samples, chunks, c, 2] fp32 */
+  float* partial;      /* out: [samples, chunks, groups, 2] fp32 (sum x, sum x^2) per row chunk and group */
   int32_t chunks;
-  float* scale_shift;  /* out: [samples, c, 2] fp32 (scale, shift) */
-  float* mean_rstd;    /* out: [samples, groups, 2] fp32 (kept for backward) */
+  float* scale_shift;  /* unused by the two-stage path (kept for layout stability); may be NULL */
+  float* mean_rstd;    /* single-launch variant only: out [samples, groups, 2] fp32 (the two-stage path writes it from the apply launch) */
 } lvd_gn_stats_params;
 int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream);
 
@@ -144,9 +145,12 @@ typedef struct {
   const lvd_bf16* x1; const lvd_bf16* x2;
   int32_t ld1, ld2, c1, c;
   int32_t rows, rows_per_sample;
-  const float* scale_shift;   /* [samples, c, 2] */
+  const float* partial;       /* [samples, chunks, groups, 2] from lvdhip_groupnorm_stats (unused by the single-launch variant) */
   int32_t silu;
   lvd_bf16* y; int32_t ldy;
+  int32_t chunks, groups; float eps;
+  const float* gamma; const float* beta;  /* [c] */
+  float* mean_rstd;           /* out: [samples, groups, 2] fp32 (kept for backward) or NULL */
 } lvd_gn_apply_params;
 int lvdhip_groupnorm_apply(const lvd_gn_apply_params* p, void* stream);
 
@@ -158,8 +162,8 @@ typedef struct {
   int32_t rows, rows_per_sample, groups;
   const float* gamma; const float* beta;
   const float* mean_rstd;     /* [samples, groups, 2] */
-  float* partial; int32_t chunks;  /* [samples, chunks, c, 2] */
-  float* gsum;                /* out: [samples, groups, 2] = (mean_g(g), mean_g(g*xhat)) */
+  float* partial; int32_t chunks;  /* out: [samples, chunks, groups, 2] = sums of (g, g*xhat) per row chunk and group */
+  float* gsum;                /* unused (kept for layout stability); may be NULL */
   int32_t silu;
 } lvd_gn_bwd_stats_params;
 int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void* stream);
@@ -169,10 +173,11 @@ typedef struct {
   const lvd_bf16* dy; int32_t lddy;
   int32_t rows, rows_per_sample, groups;
   const float* gamma; const float* beta;
-  const float* mean_rstd; const float* gsum;
+  const float* mean_rstd; const float* partial;  /* partial: [samples, chunks, groups, 2] from lvdhip_groupnorm_bwd_stats, folded by every workgroup */
   int32_t silu;
   lvd_bf16* dx1; lvd_bf16* dx2; int32_t lddx1, lddx2;  /* grads of the two sources */
   int32_t accumulate;         /* 1: dx += */
+  int32_t chunks;             /* row chunks of `partial` (unused by the single-launch variant) */
 } lvd_gn_bwd_apply_params;
 int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream);
 

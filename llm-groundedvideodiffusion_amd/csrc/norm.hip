@@ -5,9 +5,10 @@
 // ResnetBlock2D / Transformer2DModel, F*H*W rows for the 5-D norms of TemporalConvLayer /
 // TransformerTemporalModel — the (B·F,C,H,W)->(B,C,F,H,W) permute of the reference,
 // models/transformer_temporal.py:148-153, is just a different rows_per_sample here).
-// Statistics are two-stage and deterministic: per-channel partial sums per row-chunk
-// (coalesced 8-byte loads, each thread owns 4 channels), then a finalize that folds chunks and the
-// channels of a group and emits per-(sample,channel) scale/shift so the apply pass is one FMA.
+// Statistics are two-stage and deterministic: per-(row chunk, group) partial sums (coalesced 16-byte loads, each
+// thread owns 8 channels; the channels of a group are folded inside the workgroup), and the APPLY kernel folds the
+// chunks of its sample itself (fixed order, a few KB from L2 per workgroup) — there is no finalize launch between
+// the two passes (round 3: 2328 launches of 5.7 us per 8 steps that did nothing else).
 #include "common.h"
 
 namespace {
@@ -24,8 +25,10 @@ LVD_DEV void load8(const lvd_bf16* x1, const lvd_bf16* x2, int ld1, int ld2, int
   unpack8((c < c1) ? ldg16(x1 + row * ld1 + c) : ldg16(x2 + row * ld2 + (c - c1)), v);
 }
 
-// Fold the RL row-lanes of a block: red is [RL][VC][16] (8 first-moment, 8 second-moment sums per 8-channel vector).
-LVD_DEV void gn_fold_rows(float* red, float s1[8], float s2[8], int VC, int RL, int vcid, int rl, bool live, float* out) {
+// Fold the RL row-lanes of a block and then the channels of each group: red is [RL][VC][16] (8 first-moment, 8 second-moment
+// sums per 8-channel vector); out = the (sum1, sum2) pair of every group for this (sample, chunk).
+LVD_DEV void gn_fold_rows_groups(float* red, float s1[8], float s2[8], int VC, int RL, int vcid, int rl, bool live, int c, int groups,
+                                 float* out) {
   if (live) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[(rl * VC + vcid) * 16 + e] = s1[e]; red[(rl * VC + vcid) * 16 + 8 + e] = s2[e]; }
@@ -35,43 +38,73 @@ LVD_DEV void gn_fold_rows(float* red, float s1[8], float s2[8], int VC, int RL, 
     for (int q = 1; q < RL; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] += red[(q * VC + vcid) * 16 + e]; s2[e] += red[(q * VC + vcid) * 16 + 8 + e]; }
+    // row lane 0 owns slot [0][vcid] (nobody else reads it): per-channel totals of the chunk
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
+    for (int e = 0; e < 8; ++e) { red[vcid * 16 + e] = s1[e]; red[vcid * 16 + 8 + e] = s2[e]; }
+  }
+  __syncthreads();
+  const int cpg = c / groups;
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const int ch = g * cpg + cc;
+      a += red[(ch >> 3) * 16 + (ch & 7)];
+      b += red[(ch >> 3) * 16 + 8 + (ch & 7)];
+    }
+    out[g * 2] = a; out[g * 2 + 1] = b;
   }
 }
 
-// Sum the (chunk, channel-of-group) partial pairs of one (sample, group) with the whole block: independent loads, one
-// memory round trip deep whatever the chunk count.  Returns the totals in every thread.
-LVD_DEV void gn_group_totals(const float* partial, int chunks, int c, int cpg, int s, int g, float& a, float& b) {
-  __shared__ float wsum[2][4];
-  a = 0.f; b = 0.f;
-  const int n = chunks * cpg;
-  const float* base = partial + ((long)s * chunks * c + g * cpg) * 2;
-  // four pairs in flight per thread (clamped index, masked value): the partials were written by another kernel, i.e. they
-  // come from the memory side, and one pair per round trip made this tiny kernel cost 8 us
-  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
-    float2 v[4];
+// Totals of sample s over its row chunks, for every group, by the whole block, in a fixed order (thread (part, g) adds the chunks
+// part, part + parts, ...; then the parts are added in sequence): tot[g] = (sum1, sum2).  `partial` is [samples][chunks][groups][2].
+constexpr int GN_PARTS = 16, GN_MAXG = 128;
+LVD_DEV void gn_fold_chunks(const float* partial, int chunks, int groups, int s, float2* tot) {
+  __shared__ float2 scratch[GN_PARTS * GN_MAXG];
+  const int T = blockDim.x;
+  int parts = T / groups;
+  parts = parts < 1 ? 1 : (parts > GN_PARTS ? GN_PARTS : parts);
+  if (parts > chunks) parts = chunks;
+  const float2* base = reinterpret_cast<const float2*>(partial) + (long)s * chunks * groups;
+  for (int idx = threadIdx.x; idx < parts * groups; idx += T) {
+    const int part = idx / groups, g = idx - part * groups;
+    float a = 0.f, b = 0.f;
+    // eight chunks of this thread in flight at once (clamped index, masked value): the partials come from the memory side and the fold
+    // sits in front of the whole workgroup's work — at most two round trips (256 chunks over 16 parts)
+    if (chunks > 4 * parts) {
+      for (int ch0 = part; ch0 < chunks; ch0 += 8 * parts) {
+        float2 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = min(i0 + u * 256, n - 1);
-      const int ch = i / cpg, cc = i - ch * cpg;
-      v[u] = *reinterpret_cast<const float2*>(base + ((long)ch * c + cc) * 2);
-    }
+        for (int u = 0; u < 8; ++u) v[u] = base[(long)min(ch0 + u * parts, chunks - 1) * groups + g];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float w = i0 + u * 256 < n ? 1.f : 0.f;
-      a += w * v[u].x; b += w * v[u].y;
+        for (int u = 0; u < 8; ++u) {
+          const float w = ch0 + u * parts < chunks ? 1.f : 0.f;
+          a += w * v[u].x; b += w * v[u].y;
+        }
+      }
+    } else {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = base[(long)min(part + u * parts, chunks - 1) * groups + g];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float w = part + u * parts < chunks ? 1.f : 0.f;
+        a += w * v[u].x; b += w * v[u].y;
+      }
     }
+    scratch[idx] = make_float2(a, b);
   }
-  a = wave_sum(a); b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = a; wsum[1][threadIdx.x >> 6] = b; }
   __syncthreads();
-  a = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-  b = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+  for (int g = threadIdx.x; g < groups; g += T) {
+    float2 t = scratch[g];
+    for (int q = 1; q < parts; ++q) { t.x += scratch[q * groups + g].x; t.y += scratch[q * groups + g].y; }
+    tot[g] = t;
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------ GroupNorm forward stats
 // grid (chunks, samples); block = VC*RL threads (VC = c/8 channel-octets: 16-byte loads, RL row lanes)
+template <int U>  // rows in flight per thread and trip: 8 when a row lane walks >= 8 rows (few, fat chunks: the 5-D norms), else 4
 __global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
   extern __shared__ float red[];  // [RL][VC][16]
   const int t = threadIdx.x;
@@ -89,12 +122,12 @@ __global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
     const bool first = c < p.c1;  // select the source pointer once: one load instruction, no branch around it
     const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
     const int ldx = first ? p.ld1 : p.ld2;
-    for (int r0 = rbeg + rl; r0 < rend; r0 += 4 * RL) {
-      uint4 raw[4];
+    for (int r0 = rbeg + rl; r0 < rend; r0 += U * RL) {
+      uint4 raw[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);
+      for (int u = 0; u < U; ++u) raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         float v[8];
         unpack8(raw[u], v);
         const float w = r0 + u * RL < rend ? 1.f : 0.f;
@@ -103,60 +136,68 @@ __global__ void gn_partial_kernel(const lvd_gn_stats_params p, int VC, int RL) {
       }
     }
   }
-  gn_fold_rows(red, s1, s2, VC, RL, vcid, rl, live, p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2);
-}
-
-// one 256-thread block per (sample, group)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const lvd_gn_stats_params p) {
-  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
-  const int cpg = p.c / p.groups;
-  float a, b;
-  gn_group_totals(p.partial, p.chunks, p.c, cpg, s, g, a, b);
-  float cnt = (float)cpg * (float)p.rows_per_sample;
-  float mean = a / cnt;
-  float var = fmaxf(b / cnt - mean * mean, 0.f);
-  float rstd = rsqrtf(var + p.eps);
-  if (threadIdx.x == 0 && p.mean_rstd) {
-    p.mean_rstd[((long)s * p.groups + g) * 2] = mean;
-    p.mean_rstd[((long)s * p.groups + g) * 2 + 1] = rstd;
-  }
-  for (int cc = threadIdx.x; cc < cpg; cc += 256) {
-    int c = g * cpg + cc;
-    float ga = p.gamma[c], be = p.beta[c];
-    p.scale_shift[((long)s * p.c + c) * 2] = rstd * ga;
-    p.scale_shift[((long)s * p.c + c) * 2 + 1] = be - mean * rstd * ga;
-  }
+  gn_fold_rows_groups(red, s1, s2, VC, RL, vcid, rl, live, p.c, p.groups, p.partial + ((long)s * p.chunks + chunk) * p.groups * 2);
 }
 
 // ------------------------------------------------------------------ GroupNorm apply (+SiLU)
-// grid (chunks, samples); block = VC*RL threads: a thread keeps the scale/shift of its 8 channels in registers and walks rows
-__global__ void gn_apply_kernel(const lvd_gn_apply_params p, int VC, int RL, int chunks) {
+// grid (chunks, samples); block = VC*RL threads.  Prologue: the block folds the chunk partials of its sample into the group
+// statistics (gn_fold_chunks) and every thread forms scale = rstd*gamma, shift = beta - mean*rstd*gamma of its 8 channels in
+// registers; then it walks rows.  Block (0, s) also writes mean / rstd of sample s for the backward.
+__global__ __launch_bounds__(1024, 6) void gn_apply_kernel(const lvd_gn_apply_params p, int VC, int RL, int chunks) {
+  __shared__ float2 tot[GN_MAXG];
   const int t = threadIdx.x;
   const int vcid = t % VC, rl = t / VC;
-  if (rl >= RL) return;
   const int chunk = blockIdx.x, s = blockIdx.y;
   const int rps = p.rows_per_sample;
+  const int cpg = p.c / p.groups;
+  const bool live = rl < RL;
+  const int c = live ? vcid * 8 : 0;
+  // gamma / beta do not depend on the fold: their loads overlap it
+  f32x4 gv[2], bv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    gv[q] = *reinterpret_cast<const f32x4*>(p.gamma + c + 4 * q);
+    bv[q] = *reinterpret_cast<const f32x4*>(p.beta + c + 4 * q);
+  }
+  // the first trip's rows do not depend on the statistics either
   const int rpc = (rps + chunks - 1) / chunks;
   const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
-  const int c = vcid * 8;
-  float sc[8], sh[8];
-  {
-    const float* ss = p.scale_shift + ((long)s * p.c + c) * 2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(ss + 4 * q);
-      sc[2 * q] = v[0]; sh[2 * q] = v[1]; sc[2 * q + 1] = v[2]; sh[2 * q + 1] = v[3];
-    }
-  }
   const bool first = c < p.c1;
   const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
   const int ldx = first ? p.ld1 : p.ld2;
+  uint4 raw[4];
+  {
+    const int r0 = min(rbeg + (live ? rl : 0), rend - 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);  // clamped, not predicated
+  }
+  gn_fold_chunks(p.partial, p.chunks, p.groups, s, tot);
+  const float cnt = (float)cpg * (float)rps;
+  if (chunk == 0 && p.mean_rstd) {
+    for (int g = t; g < p.groups; g += blockDim.x) {
+      const float mean = tot[g].x / cnt;
+      const float var = fmaxf(tot[g].y / cnt - mean * mean, 0.f);
+      p.mean_rstd[((long)s * p.groups + g) * 2] = mean;
+      p.mean_rstd[((long)s * p.groups + g) * 2 + 1] = rsqrtf(var + p.eps);
+    }
+  }
+  if (!live) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float2 ab = tot[(c + e) / cpg];
+    const float mean = ab.x / cnt;
+    const float var = fmaxf(ab.y / cnt - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps);
+    const float ga = gv[e >> 2][e & 3], be = bv[e >> 2][e & 3];
+    sc[e] = rstd * ga;
+    sh[e] = be - mean * rstd * ga;
+  }
   // four rows per trip: the loads are issued together (the stores may alias them for all the compiler knows)
   for (int r0 = rbeg + rl; r0 < rend; r0 += 4 * RL) {
-    uint4 raw[4];
+    if (r0 != rbeg + rl) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);  // clamped, not predicated
+      for (int u = 0; u < 4; ++u) raw[u] = ldg16(xb + ((long)s * rps + min(r0 + u * RL, rend - 1)) * ldx);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -177,7 +218,7 @@ __global__ void gn_apply_kernel(const lvd_gn_apply_params p, int VC, int RL, int
 }
 
 // ------------------------------------------------------------------ GroupNorm backward
-// per-channel partials of (g, g*xhat), g = dy * silu'(yhat) * gamma
+// per-(chunk, group) partials of (g, g*xhat), g = dy * silu'(yhat) * gamma
 __global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, int RL) {
   extern __shared__ float red[];
   const int t = threadIdx.x;
@@ -227,40 +268,37 @@ __global__ void gn_bwd_partial_kernel(const lvd_gn_bwd_stats_params p, int VC, i
       }
     }
   }
-  gn_fold_rows(red, s1, s2, VC, RL, vcid, rl, live, p.partial + (((long)s * p.chunks + chunk) * p.c + c) * 2);
+  gn_fold_rows_groups(red, s1, s2, VC, RL, vcid, rl, live, p.c, p.groups, p.partial + ((long)s * p.chunks + chunk) * p.groups * 2);
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const lvd_gn_bwd_stats_params p) {
-  const int s = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
-  const int cpg = p.c / p.groups;
-  float a, b;
-  gn_group_totals(p.partial, p.chunks, p.c, cpg, s, g, a, b);
-  float cnt = (float)cpg * (float)p.rows_per_sample;
-  if (threadIdx.x == 0) {
-    p.gsum[((long)s * p.groups + g) * 2] = a / cnt;
-    p.gsum[((long)s * p.groups + g) * 2 + 1] = b / cnt;
-  }
-}
-
+// grid (chunks, samples); the block folds the backward partials of its sample first (as gn_apply_kernel does for the forward)
 __global__ void gn_bwd_apply_kernel(const lvd_gn_bwd_apply_params p, int VC, int RL, int chunks) {
+  __shared__ float2 tot[GN_MAXG];
   const int t = threadIdx.x;
   const int vcid = t % VC, rl = t / VC;
-  if (rl >= RL) return;
   const int chunk = blockIdx.x, s = blockIdx.y;
   const int rps = p.rows_per_sample;
-  const int rpc = (rps + chunks - 1) / chunks;
-  const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
-  const int c = vcid * 8;
   const int cpg = p.c / p.groups;
+  const bool live = rl < RL;
+  const int c = live ? vcid * 8 : 0;
   float mean[8], rstd[8], m1[8], m2[8], ga[8], be[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int g = (c + e) / cpg;
     float2 mr = *reinterpret_cast<const float2*>(p.mean_rstd + ((long)s * p.groups + g) * 2);
-    float2 gs = *reinterpret_cast<const float2*>(p.gsum + ((long)s * p.groups + g) * 2);
-    mean[e] = mr.x; rstd[e] = mr.y; m1[e] = gs.x; m2[e] = gs.y;
+    mean[e] = mr.x; rstd[e] = mr.y;
     ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e];
   }
+  gn_fold_chunks(p.partial, p.chunks, p.groups, s, tot);
+  if (!live) return;
+  const float cnt = (float)cpg * (float)rps;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float2 ab = tot[(c + e) / cpg];
+    m1[e] = ab.x / cnt; m2[e] = ab.y / cnt;
+  }
+  const int rpc = (rps + chunks - 1) / chunks;
+  const int rbeg = chunk * rpc, rend = min(rps, rbeg + rpc);
   const bool first = c < p.c1;
   const lvd_bf16* xb = first ? p.x1 + c : p.x2 + (c - p.c1);
   const int ldx = first ? p.ld1 : p.ld2;
@@ -536,9 +574,11 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const lvd_ln_bwd_param
   }
 }
 
-// row chunks per sample for the elementwise passes: ~8 workgroups per CU over the whole launch, >= 4 rows per row lane
+// row chunks per sample for the elementwise passes: ~3 workgroups per CU over the whole launch (one resident round: every workgroup
+// of a sample repeats the fold of its statistics partials, so few fat workgroups beat many thin ones), >= 4 rows per row lane
 int gn_row_chunks(int samples, int rows_per_sample, int RL) {
-  int want = (2048 + samples - 1) / samples;
+  int want = (768 + samples - 1) / samples;
+  if (want > 512) want = 512;
   int most = rows_per_sample / (4 * RL);
   if (want > most) want = most;
   return want < 1 ? 1 : want;
@@ -556,7 +596,8 @@ int gn_geometry(int c, int* VC, int* RL, int* threads) {
 }  // namespace
 
 extern "C" int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream) {
-  LVD_CHECK(p && p->x1 && p->partial && p->scale_shift, "gn_stats: null pointer");
+  LVD_CHECK(p && p->x1 && p->partial, "gn_stats: null pointer");
+  LVD_CHECK(p->groups >= 1 && p->groups <= GN_MAXG, "gn_stats: groups=%d unsupported (1..%d)", p->groups, GN_MAXG);
   LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->c % p->groups == 0, "gn_stats: bad channels c=%d c1=%d groups=%d", p->c, p->c1, p->groups);
   LVD_CHECK(p->rows % p->rows_per_sample == 0 && p->chunks > 0, "gn_stats: rows %% rows_per_sample");
   LVD_CHECK(p->x2 != nullptr || p->c1 >= p->c, "gn_stats: missing second source");
@@ -564,16 +605,17 @@ extern "C" int lvdhip_groupnorm_stats(const lvd_gn_stats_params* p, void* stream
   LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_stats: c too large");
   int samples = p->rows / p->rows_per_sample;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 16 * sizeof(float), s, *p, VC, RL);
-  LVD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(samples * p->groups), dim3(256), 0, s, *p);
+  const int rpc = (p->rows_per_sample + p->chunks - 1) / p->chunks;
+  if (rpc >= 8 * RL) hipLaunchKernelGGL(gn_partial_kernel<8>, dim3(p->chunks, samples), dim3(threads), VC * RL * 16 * sizeof(float), s, *p, VC, RL);
+  else hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(p->chunks, samples), dim3(threads), VC * RL * 16 * sizeof(float), s, *p, VC, RL);
   LVD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int lvdhip_groupnorm_apply(const lvd_gn_apply_params* p, void* stream) {
-  LVD_CHECK(p && p->x1 && p->y && p->scale_shift, "gn_apply: null pointer");
+  LVD_CHECK(p && p->x1 && p->y && p->partial && p->gamma && p->beta, "gn_apply: null pointer");
   LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0, "gn_apply: channels must be multiples of 8");
+  LVD_CHECK(p->groups >= 1 && p->groups <= GN_MAXG && p->c % p->groups == 0 && p->chunks > 0, "gn_apply: bad groups=%d / chunks=%d", p->groups, p->chunks);
   LVD_CHECK(p->rows % p->rows_per_sample == 0, "gn_apply: rows %% rows_per_sample");
   int VC, RL, threads;
   LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_apply: c too large");
@@ -585,21 +627,20 @@ extern "C" int lvdhip_groupnorm_apply(const lvd_gn_apply_params* p, void* stream
 }
 
 extern "C" int lvdhip_groupnorm_bwd_stats(const lvd_gn_bwd_stats_params* p, void* stream) {
-  LVD_CHECK(p && p->x1 && p->dy && p->partial && p->gsum && p->mean_rstd, "gn_bwd_stats: null pointer");
-  LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->c % p->groups == 0, "gn_bwd_stats: bad channels");
+  LVD_CHECK(p && p->x1 && p->dy && p->partial && p->mean_rstd, "gn_bwd_stats: null pointer");
+  LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->groups >= 1 && p->groups <= GN_MAXG && p->c % p->groups == 0, "gn_bwd_stats: bad channels");
   int VC, RL, threads;
   LVD_CHECK(gn_geometry(p->c, &VC, &RL, &threads) == 0, "gn_bwd_stats: c too large");
   int samples = p->rows / p->rows_per_sample;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(p->chunks, samples), dim3(threads), VC * RL * 16 * sizeof(float), s, *p, VC, RL);
   LVD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(samples * p->groups), dim3(256), 0, s, *p);
-  LVD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream) {
-  LVD_CHECK(p && p->x1 && p->dy && p->dx1 && p->gsum, "gn_bwd_apply: null pointer");
+  LVD_CHECK(p && p->x1 && p->dy && p->dx1 && p->partial && p->mean_rstd, "gn_bwd_apply: null pointer");
+  LVD_CHECK(p->groups >= 1 && p->groups <= GN_MAXG && p->c % p->groups == 0 && p->chunks > 0, "gn_bwd_apply: bad groups=%d / chunks=%d", p->groups, p->chunks);
   LVD_CHECK(p->x2 == nullptr || p->dx2 != nullptr, "gn_bwd_apply: dx2 missing");
   LVD_CHECK(p->c % 8 == 0 && p->c1 % 8 == 0 && p->rows % p->rows_per_sample == 0, "gn_bwd_apply: bad shape");
   int VC, RL, threads;

@@ -43,8 +43,9 @@ class GnStatsParams(C.Structure):
 class GnApplyParams(C.Structure):
     _fields_ = [
         ("x1", C.c_void_p), ("x2", C.c_void_p), ("ld1", i32), ("ld2", i32), ("c1", i32), ("c", i32),
-        ("rows", i32), ("rows_per_sample", i32), ("scale_shift", C.c_void_p), ("silu", i32),
-        ("y", C.c_void_p), ("ldy", i32),
+        ("rows", i32), ("rows_per_sample", i32), ("partial", C.c_void_p), ("silu", i32),
+        ("y", C.c_void_p), ("ldy", i32), ("chunks", i32), ("groups", i32), ("eps", f32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p),
     ]
 
 
@@ -63,9 +64,9 @@ class GnBwdApplyParams(C.Structure):
         ("x1", C.c_void_p), ("x2", C.c_void_p), ("ld1", i32), ("ld2", i32), ("c1", i32), ("c", i32),
         ("dy", C.c_void_p), ("lddy", i32),
         ("rows", i32), ("rows_per_sample", i32), ("groups", i32),
-        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p), ("gsum", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p), ("partial", C.c_void_p),
         ("silu", i32),
-        ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("lddx1", i32), ("lddx2", i32), ("accumulate", i32),
+        ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("lddx1", i32), ("lddx2", i32), ("accumulate", i32), ("chunks", i32),
     ]
 
 
@@ -180,7 +181,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 101
+ABI_VERSION = 102
 
 
 def lib():

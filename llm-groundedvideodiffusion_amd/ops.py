@@ -216,14 +216,29 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     return out
 
 
+GN_MAX_CHUNKS = 256
+
+
 def _gn_chunks(samples, rows_per_sample, min_rows=64):
-    # enough workgroups to fill 256 CUs a few times over, but >= min_rows rows per chunk (every chunk costs the finalize pass a read)
-    want = max(1, 2048 // max(samples, 1))
+    # one resident round of workgroups on 256 CUs (3 per CU), but >= min_rows rows per chunk, and at most GN_MAX_CHUNKS per sample: every
+    # workgroup of the apply pass folds the [chunks, groups] partials of its sample itself (no finalize launch), 8 bytes * groups per chunk
+    want = max(1, min(768 // max(samples, 1), GN_MAX_CHUNKS))
     return max(1, min(want, rows_per_sample // min_rows if rows_per_sample >= min_rows else 1))
 
 
+@dataclass
+class GnStats:
+    """Statistics partials of a GroupNorm ([samples, chunks, groups, 2] sums) plus what the apply launch needs to finish them."""
+    partial: torch.Tensor
+    chunks: int
+    groups: int
+    eps: float
+    gamma: torch.Tensor
+    beta: torch.Tensor
+
+
 def groupnorm_stats(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, x2=None):
-    """Returns (scale_shift [S,C,2], mean_rstd [S,G,2])."""
+    """First of the two launches: per-(row chunk, group) sums.  Returns GnStats for groupnorm_apply."""
     _chk_bf16(x1, x2)
     _chk_f32(gamma, beta)
     rows = x1.shape[0]
@@ -232,29 +247,30 @@ def groupnorm_stats(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, x2
     samples = rows // rows_per_sample
     chunks = _gn_chunks(samples, rows_per_sample)
     dev = x1.device
-    partial = torch.empty((samples, chunks, c, 2), dtype=torch.float32, device=dev)
-    ss = torch.empty((samples, c, 2), dtype=torch.float32, device=dev)
-    mr = torch.empty((samples, groups, 2), dtype=torch.float32, device=dev)
+    partial = torch.empty((samples, chunks, groups, 2), dtype=torch.float32, device=dev)
     p = hip.GnStatsParams()
     p.x1, p.x2, p.ld1, p.ld2, p.c1, p.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
     p.rows, p.rows_per_sample, p.groups, p.eps = rows, rows_per_sample, groups, eps
-    p.gamma, p.beta, p.partial, p.chunks, p.scale_shift, p.mean_rstd = _p(gamma), _p(beta), _p(partial), chunks, _p(ss), _p(mr)
+    p.gamma, p.beta, p.partial, p.chunks, p.scale_shift, p.mean_rstd = _p(gamma), _p(beta), _p(partial), chunks, None, None
     hip.check(hip.lib().lvdhip_groupnorm_stats(C.byref(p), _stream()), "groupnorm_stats")
-    return ss, mr
+    return GnStats(partial, chunks, groups, eps, gamma, beta)
 
 
-def groupnorm_apply(x1, scale_shift, rows_per_sample, *, silu=False, x2=None, out=None):
+def groupnorm_apply(x1, stats: GnStats, rows_per_sample, *, silu=False, x2=None, out=None):
+    """Second launch: folds the partials, normalises (+SiLU).  Returns (y, mean_rstd [S,G,2])."""
     _chk_bf16(x1, x2)
     rows = x1.shape[0]
     c1 = x1.shape[1]
     c = c1 + (x2.shape[1] if x2 is not None else 0)
     if out is None:
         out = torch.empty((rows, c), dtype=torch.bfloat16, device=x1.device)
+    mr = torch.empty((rows // rows_per_sample, stats.groups, 2), dtype=torch.float32, device=x1.device)
     p = hip.GnApplyParams()
     p.x1, p.x2, p.ld1, p.ld2, p.c1, p.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
-    p.rows, p.rows_per_sample, p.scale_shift, p.silu, p.y, p.ldy = rows, rows_per_sample, _p(scale_shift), int(silu), _p(out), _ld(out)
+    p.rows, p.rows_per_sample, p.partial, p.silu, p.y, p.ldy = rows, rows_per_sample, _p(stats.partial), int(silu), _p(out), _ld(out)
+    p.chunks, p.groups, p.eps, p.gamma, p.beta, p.mean_rstd = stats.chunks, stats.groups, stats.eps, _p(stats.gamma), _p(stats.beta), _p(mr)
     hip.check(hip.lib().lvdhip_groupnorm_apply(C.byref(p), _stream()), "groupnorm_apply")
-    return out
+    return out, mr
 
 
 # Small samples take the single-launch kernels (norm_small.hip): a (sample, group) slab of at most 64 Ki elements (128 KB: its
@@ -297,8 +313,8 @@ def groupnorm_auto(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, sil
     c = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if groupnorm_fused_ok(x1.shape[0], c, rows_per_sample, groups):
         return groupnorm_fused(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, silu=silu, x2=x2, out=out)
-    ss, mr = groupnorm_stats(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, x2=x2)
-    return groupnorm_apply(x1, ss, rows_per_sample, silu=silu, x2=x2, out=out), mr
+    st = groupnorm_stats(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, x2=x2)
+    return groupnorm_apply(x1, st, rows_per_sample, silu=silu, x2=x2, out=out)
 
 
 def groupnorm(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None, return_stats=False):
@@ -334,13 +350,12 @@ def groupnorm_bwd(x1, dy, gamma, beta, mean_rstd, rows_per_sample, *, groups=32,
     # workgroups (34 -> 25 us at 1080 rows, 39 -> 32 us at 4320 with 32-row chunks; larger samples and the forward pass do not gain)
     chunks = _gn_chunks(samples, rows_per_sample, 32 if rows_per_sample <= 8192 else 64)
     dev = x1.device
-    partial = torch.empty((samples, chunks, c, 2), dtype=torch.float32, device=dev)
-    gsum = torch.empty((samples, groups, 2), dtype=torch.float32, device=dev)
+    partial = torch.empty((samples, chunks, groups, 2), dtype=torch.float32, device=dev)
     p = hip.GnBwdStatsParams()
     p.x1, p.x2, p.ld1, p.ld2, p.c1, p.c = _p(x1), _p(x2), _ld(x1), (_ld(x2) if x2 is not None else 0), c1, c
     p.dy, p.lddy = _p(dy), _ld(dy)
     p.rows, p.rows_per_sample, p.groups = rows, rows_per_sample, groups
-    p.gamma, p.beta, p.mean_rstd, p.partial, p.chunks, p.gsum, p.silu = _p(gamma), _p(beta), _p(mean_rstd), _p(partial), chunks, _p(gsum), int(silu)
+    p.gamma, p.beta, p.mean_rstd, p.partial, p.chunks, p.gsum, p.silu = _p(gamma), _p(beta), _p(mean_rstd), _p(partial), chunks, None, int(silu)
     hip.check(hip.lib().lvdhip_groupnorm_bwd_stats(C.byref(p), _stream()), "groupnorm_bwd_stats")
     if dx1 is None:
         dx1 = torch.empty_like(x1)
@@ -351,7 +366,7 @@ def groupnorm_bwd(x1, dy, gamma, beta, mean_rstd, rows_per_sample, *, groups=32,
     q.x1, q.x2, q.ld1, q.ld2, q.c1, q.c = p.x1, p.x2, p.ld1, p.ld2, c1, c
     q.dy, q.lddy = p.dy, p.lddy
     q.rows, q.rows_per_sample, q.groups = rows, rows_per_sample, groups
-    q.gamma, q.beta, q.mean_rstd, q.gsum, q.silu = p.gamma, p.beta, p.mean_rstd, _p(gsum), int(silu)
+    q.gamma, q.beta, q.mean_rstd, q.partial, q.chunks, q.silu = p.gamma, p.beta, p.mean_rstd, _p(partial), chunks, int(silu)
     q.dx1, q.dx2 = _p(dx1), _p(dx2)
     q.lddx1, q.lddx2 = _ld(dx1), (_ld(dx2) if dx2 is not None else 0)
     q.accumulate = int(accumulate)
