@@ -111,6 +111,13 @@ typedef struct {
                               can be cut into row ranges (LVD_GEMM_V_*_TAIL variants do this internally) */
   int32_t ldrowbias;       /* row stride of rowbias in floats (0 = N): the temb projections of all ResnetBlock2Ds of a forward are ONE
                               product [B, sum of N] and each conv reads its column range of it */
+  /* LayerNorm folded into a linear product (BasicTransformerBlock.norm1/2/3 -> to_q|k|v / ff.net.0, models/attention.py:113,140,153):
+     with ln_mean_rstd set, A holds the UN-normalised rows x, `w` = gamma (.) W (bf16), `bias` = b + W beta, ln_colsum[n] = sum_k w[n,k]
+     (fp32, of the bf16-rounded w), and OUT = alpha * ( rstd_m * (x . w^T - mean_m * ln_colsum) + bias ): the normalised
+     activation is never materialised.  Plain single-source loader, no residual / accumulate / rowbias, bf16 output with N % 16 == 0;
+     asm-DMA ring and K-split variants only. */
+  const float* ln_mean_rstd;  /* [M, 2] fp32 (mean, rstd) per row of A (lvdhip_layernorm with y = NULL writes it), or NULL */
+  const float* ln_colsum;     /* [N] fp32 */
 } lvd_gemm_params;
 
 int lvdhip_gemm(const lvd_gemm_params* p, void* stream);

@@ -343,6 +343,7 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   if (v >= 300) return 3;
   if (v >= LVD_GEMM_V_ADMA64) { adma = 200; v -= LVD_GEMM_V_ADMA64; }
   else if (v >= LVD_GEMM_V_ADMA) { adma = 100; v -= LVD_GEMM_V_ADMA; }
+  if (v == 0 && !adma && p->ln_mean_rstd) { adma = 100; v = LVD_GEMM_V_RING128; }  // unpinned LayerNorm-folded product: the asm-DMA 128x128 ring
   if (v == 0) {
     if (adma) return 3;
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_variants.txt):
@@ -372,6 +373,7 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
   if (v == 11) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 4 : 5) + adma);
   if (v == 9) return lvd_gemm_ring_dispatch(p, stream, ((p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3) + a100);
   if (adma) return 3;
+  if (p->ln_mean_rstd) return 4;  // the register-staged kernels have no LayerNorm-folded epilogue
   if (v == 1) return launch_gemm<32, 3>(p, grid, s);
   if (v == 2) return launch_gemm<32, 4>(p, grid, s);
   if (v == 10) return launch_gemm<64, 2>(p, grid, s);
@@ -429,6 +431,11 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
     LVD_CHECK(p->K == 9 * p->cin && p->hout > 0 && p->wout > 0 && p->hin > 0 && p->win > 0 && p->M % (p->hout * p->wout) == 0,
               "gemm: bad conv dims");
   LVD_CHECK(p->m_begin >= 0 && p->m_begin < p->M, "gemm: m_begin %d outside [0, M=%d)", p->m_begin, p->M);
+  if (p->ln_mean_rstd)
+    LVD_CHECK(p->ln_colsum && p->mode == LVD_A_PLAIN && !p->out_fp32 && !p->rowbias && !p->res && !p->accumulate && !p->a2 && p->N % 16 == 0 &&
+                  p->ldc % 8 == 0 && p->K % 32 == 0 && (reinterpret_cast<uintptr_t>(p->out) & 15) == 0,
+              "gemm: a LayerNorm-folded product needs ln_colsum, the plain single-source loader, K%%32==0, no residual / accumulate / temb row-bias "
+              "and a 16-byte addressable bf16 output (N%%16, ldc%%8)");
   static const int variant = [] {  // developer knob for A/B runs (tools/gemm_bench.py); read once, thread-safe initialisation
     const char* e = getenv("LVD_GEMM_VARIANT");
     return e ? atoi(e) : 0;
@@ -440,6 +447,7 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
   if (vb == LVD_GEMM_V_RING256W_TAIL || vb == LVD_GEMM_V_RING128x320_TAIL) rc = run_with_tail(p, stream, v);
   else rc = run_variant(p, stream, v);
   LVD_CHECK(rc != 3, "gemm: variant %d names no tile geometry", v);
+  LVD_CHECK(rc != 4, "gemm: variant %d cannot take a LayerNorm-folded product (asm-DMA ring and K-split variants only)", v);
   LVD_CHECK(rc == 0, "gemm: unknown mode %d", p->mode);
   LVD_LAUNCH_CHECK();
   return 0;

@@ -58,8 +58,11 @@ LVD_DEV void keep_live(const T& v) { asm volatile("" ::"v"(v)); }
 // so the compiler neither sees a pending LDS write (no vmcnt(0) in front of every phase's first ds_read: the counted waits
 // really leave STAGES-2 tiles in flight) nor keeps 64-bit source addresses; rows / columns past M / N are clamped (their
 // products are never stored), K tiles past the end re-read the last one.
-template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false, bool ADMA = false>
+// LNF: the LayerNorm-folded product (lvd_gemm_params.ln_mean_rstd; gemm_tile.h LnEpi) — its own instantiation, not a runtime branch:
+// one more epilogue path inside the 251-register FN = 5 kernels made the ordinary epilogue spill.
+template <int MODE, int WM, int WN, int FM, int FN, int STAGES, int RBK, bool SPLITK = false, bool PP = false, bool ADMA = false, bool LNF = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_ring_kernel(const lvd_gemm_params p) {
+  static_assert(!LNF || (ADMA && !SPLITK), "LayerNorm fold: asm-DMA, unsplit");
   static_assert(!ADMA || (MODE == LVD_A_PLAIN && (RBK == 32 || RBK == 64)), "asm DMA: plain loader, 32- or 64-wide K tiles");
   constexpr bool PP64 = PP && RBK == 64;                 // two-slot ring of 128-byte rows, consumed in two 32-deep halves (below)
   static_assert(!PP64 || (ADMA && STAGES == 2), "PP64: asm DMA, two slots");
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   static_assert(AINS % NW == 0, "BM must be a multiple of RPI * waves");
   constexpr int LPS = APW + BPW;                         // glds per wave per stage (uniform -> one vmcnt immediate)
   constexpr int BIASQ = ADMA ? (BN * 4 + 1023) / 1024 * 64 : 0;               // ADMA: the tile's bias row is staged in LDS by the DMA engine too
-  __shared__ uint4 lds[STAGES * TILE + BIASQ + (PP ? LVD_TRQ : 0)];
+  constexpr int LNQ = LNF ? BIASQ : 0;                                         // ... and, for a LayerNorm-folded product, its colsum row
+  __shared__ uint4 lds[STAGES * TILE + BIASQ + LNQ + (PP ? LVD_TRQ : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, hi = lane >> 5;
 #ifdef LVD_TRACE
-  unsigned* tr_buf = reinterpret_cast<unsigned*>(lds + STAGES * TILE + BIASQ) + (wave >> 2) * 128;
+  unsigned* tr_buf = reinterpret_cast<unsigned*>(lds + STAGES * TILE + BIASQ + LNQ) + (wave >> 2) * 128;
   int tr_n = 0;
   const bool tr_blk = PP && (int)blockIdx.x == (int)(gridDim.x / 2) && (wave & 3) == 0;
   bool tr_on = false;
@@ -185,9 +189,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   const int nk = (max(klim - kbeg, 0) + RBK - 1) / RBK;
 
   if constexpr (ADMA && !SPLITK) {
-    if (p.bias && wave * 256 < BN * 4) {
+    if (p.bias && wave * 256 < BN) {
       const int off = min(tn * BN * 4 + wave * 1024 + lane * 16, p.N * 4 - 16);
       dma16(make_rsrc(p.bias), off, 0, lds_addr(lds + STAGES * TILE + wave * 64));
+    }
+    if constexpr (LNF) {
+      if (wave * 256 < BN) {
+        const int off = min(tn * BN * 4 + wave * 1024 + lane * 16, p.N * 4 - 16);
+        dma16(make_rsrc(p.ln_colsum), off, 0, lds_addr(lds + STAGES * TILE + BIASQ + wave * 64));
+      }
     }
   }
   // prologue: STAGES-1 tiles in flight (tiles beyond nk are staged from the zero page: uniform vmcnt bookkeeping)
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   }
 
   auto acc_from_lds_bias = [&]() {  // after a barrier that follows the waves' wait for the bias DMA
-    if (p.bias) {
+    if (p.bias && !LNF) {  // (a LayerNorm-folded product adds its bias behind the row scaling: ring_epilogue_rows)
       const uint4* bq = lds + STAGES * TILE + wn * FN * 8 + hi;
 #pragma unroll
       for (int j = 0; j < FN; ++j)
@@ -435,6 +445,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
       slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
   }
+  // LayerNorm-folded product: (mean, rstd) of this lane's FM rows.  Loaded here, behind the main loop (the fragment registers are dead
+  // now; four more live registers across the loop made the FN = 5 tiles spill), in front of the final wait + barrier that cover them.
+  [[maybe_unused]] LnEpi<FM> lnepi;
+  if constexpr (LNF) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = min(p.m_begin + tm * BM + (wm * FM + i) * 32 + l31, p.M - 1);
+      const float2 mr = *reinterpret_cast<const float2*>(p.ln_mean_rstd + 2L * m);
+      lnepi.mean[i] = mr.x; lnepi.rstd[i] = mr.y;
+    }
+  }
   wait_vmcnt<0>();
 #ifdef LVD_TRACE
   if constexpr (PP) {
@@ -476,7 +497,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : 2)) void gemm_rin
   constexpr int WAVE_DW = STAGES * TILE * 4 / NW;
   static_assert(WAVE_DW >= 32 * (FN * 16 + 2), "ring too small for the epilogue strip");
   __builtin_amdgcn_s_barrier();  // all waves are done reading the last K tile (and every DMA has landed: vmcnt(0) above)
-  ring_epilogue_auto<FM, FN>(p, acc, mbase, nbase, lane, reinterpret_cast<uint32_t*>(lds) + wave * WAVE_DW);
+  if constexpr (LNF) {
+    lnepi.b = reinterpret_cast<const float*>(lds + STAGES * TILE) + wn * FN * 32;
+    lnepi.s = reinterpret_cast<const float*>(lds + STAGES * TILE + BIASQ) + wn * FN * 32;
+    if (p.act == LVD_ACT_GEGLU) {
+      if constexpr (FN % 2 == 0) ring_epilogue_rows<FM, FN, true, RowsLinear, true>(p, acc, RowsLinear{mbase}, nbase, lane, reinterpret_cast<uint32_t*>(lds) + wave * WAVE_DW, &lnepi);
+    } else {
+      ring_epilogue_rows<FM, FN, false, RowsLinear, true>(p, acc, RowsLinear{mbase}, nbase, lane, reinterpret_cast<uint32_t*>(lds) + wave * WAVE_DW, &lnepi);
+    }
+  } else {
+    ring_epilogue_auto<FM, FN>(p, acc, mbase, nbase, lane, reinterpret_cast<uint32_t*>(lds) + wave * WAVE_DW);
+  }
 }
 
 // deterministic slab reduction + the usual epilogue (bias, temb row-bias, gate, residual, accumulate)
@@ -542,6 +573,15 @@ int launch_ring(const lvd_gemm_params* p, hipStream_t s) {
   constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
   int tiles = ((p->M - p->m_begin + BM - 1) / BM) * ((p->N + BN - 1) / BN);
   dim3 grid(tiles), block(64 * WM * WN);
+  if constexpr (ADMA) {
+    if (p->ln_mean_rstd) {  // LayerNorm-folded product (GEGLU needs an even fragment count: the FN = 5 tiles do not take it)
+      if (p->mode != LVD_A_PLAIN || (p->act == LVD_ACT_GEGLU && FN % 2)) return 4;
+      hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, false, PP, true, true>), grid, block, 0, s, *p);
+      return 0;
+    }
+  } else {
+    if (p->ln_mean_rstd) return 4;
+  }
   switch (p->mode) {
     case LVD_A_PLAIN: hipLaunchKernelGGL((gemm_ring_kernel<LVD_A_PLAIN, WM, WN, FM, FN, STAGES, RBK, false, PP, ADMA>), grid, block, 0, s, *p); break;
     default:

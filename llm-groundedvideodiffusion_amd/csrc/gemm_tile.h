@@ -247,6 +247,17 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
   }
 }
 
+// LayerNorm folded into the product (lvd_gemm_params.ln_mean_rstd): the MFMAs run on the raw rows x and on W' = gamma (.) W, and
+// the epilogue turns the accumulator into  rstd_m * (acc - mean_m * colsum_n) + bias_n  (colsum_n = sum_k W'_nk, bias_n = b_n +
+// sum_k beta_k W_nk, both prepared by the host) — the normalised activation is never written or read.  mean / rstd of the FM row
+// blocks of this lane, and the tile's bias / colsum rows in LDS (already offset to this wave's first column).
+template <int FM>
+struct LnEpi {
+  float mean[FM], rstd[FM];
+  const float* b;
+  const float* s;
+};
+
 // Coalesced epilogue.  The register-direct form above writes 16 bytes per token row per store instruction (32 rows, 32
 // different cache lines): on the short-K layers, where the output is as large as the input, those partial-line stores
 // were the longest phase of the kernel.  Here each wave transposes its accumulators through a private LDS strip
@@ -254,8 +265,9 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
 // consecutive lanes cover consecutive bytes of a row: full 128-byte lines for the store and for the residual /
 // accumulate read.  The residual is added in fp32 to the bf16-rounded projection (what the reference's separate
 // residual add does).  Wave-private: no workgroup barrier, the LDS queue keeps one wave's accesses in order.
-template <int FM, int FN, bool GEGLU, class RM>
-LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], const RM& rm, int nbase, int lane, uint32_t* buf) {
+template <int FM, int FN, bool GEGLU, class RM, bool LN = false>
+LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN], const RM& rm, int nbase, int lane, uint32_t* buf,
+                                const LnEpi<FM>* ln = nullptr) {
   constexpr int W = GEGLU ? FN * 16 : FN * 32;  // output columns of this wave
   constexpr int S = W / 2 + 2;                  // dwords per staged row: S = 2 (mod 4) -> the 32 rows of a ds_write_b64 hit 32 distinct
                                                 // bank pairs (conflict-free); rows are 8-byte aligned, so the read side uses two b64
@@ -274,7 +286,8 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
     // of that branch (vmcnt(0) after every load), which is exactly the serialisation this prefetch exists to avoid.
     uint4 rres[PASSES], racc[PASSES];
     static_assert((32 * CPR) % 64 == 0, "whole passes");
-    if (p.res) {
+    constexpr bool SIDE = !LN;  // a LayerNorm-folded product has neither residual nor accumulate operand (lvdhip_gemm checks): no prefetch registers
+    if (SIDE && p.res) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * 64 + lane;
@@ -284,7 +297,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
         rres[ps] = ldg16(p.res + (long)mm * p.ldres + n);
       }
     }
-    if (p.accumulate) {
+    if (SIDE && p.accumulate) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
         const int idx = ps * 64 + lane;
@@ -303,6 +316,16 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
           f32x4 h, g;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
+          if constexpr (LN) {
+            const int nl = b * 64 + 8 * q + 4 * hi;
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(ln->s + nl), sg = *reinterpret_cast<const f32x4*>(ln->s + nl + 32);
+            const f32x4 bh = *reinterpret_cast<const f32x4*>(ln->b + nl), bg = *reinterpret_cast<const f32x4*>(ln->b + nl + 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              h[e] = fmaf(ln->rstd[i], fmaf(-ln->mean[i], sh[e], h[e]), bh[e]);
+              g[e] = fmaf(ln->rstd[i], fmaf(-ln->mean[i], sg[e], g[e]), bg[e]);
+            }
+          }
           uint2 o;
           o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
           o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
@@ -317,6 +340,12 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+          if constexpr (LN) {
+            const int nl = j * 32 + 8 * q + 4 * hi;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(ln->s + nl), bv = *reinterpret_cast<const f32x4*>(ln->b + nl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(ln->rstd[i], fmaf(-ln->mean[i], sv[e], v[e]), bv[e]);
+          }
           v *= p.alpha;
           uint2 o;
           o.x = pack2bf(v[0], v[1]);
@@ -338,7 +367,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
         const uint2 vhi = *reinterpret_cast<const uint2*>(buf + r * S + c * 4 + 2);
         uint4 v = make_uint4(vlo.x, vlo.y, vhi.x, vhi.y);
         lvd_bf16* o = out + (long)mm * p.ldc + n;
-        if (p.res || p.accumulate) {
+        if (SIDE && (p.res || p.accumulate)) {
           float f[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
           if (p.res) {
             uint4 t = rres[ps];
@@ -438,6 +467,12 @@ LVD_DEV void splitk_reduce_quad(const lvd_gemm_params& p, const float* s0, long 
     if (s < p.ksplit) v += a;
     if (s + 1 < p.ksplit) v += b;
     if (s + 2 < p.ksplit) v += c;
+  }
+  if (p.ln_mean_rstd) {  // LayerNorm folded into the product (LnEpi above): the slices hold x . W'^T
+    const float2 mr = *reinterpret_cast<const float2*>(p.ln_mean_rstd + 2L * m);
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mr.y * fmaf(-mr.x, cs[e], v[e]);
   }
   if (p.bias) v += bv;
   if (p.rowbias) v += rbv;

@@ -375,6 +375,7 @@ __global__ void ln_fwd_kernel(const lvd_ln_params p) {
   }
   float rstd = rsqrtf(wave_sum(q) / (float)p.c + p.eps);
   if (lane == 0 && p.mean_rstd) { p.mean_rstd[row * 2] = mean; p.mean_rstd[row * 2 + 1] = rstd; }
+  if (!p.y) return;  // statistics only
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j) {
     int v = lane + 64 * j;
@@ -395,15 +396,16 @@ __global__ void ln_fwd_kernel(const lvd_ln_params p) {
 // one-wave-per-row kernel above keeps 40 of 64 lanes busy at C = 320, one load in flight per lane, and re-reads gamma /
 // beta (4x the bytes of the row itself) for every row.
 constexpr int LN_BATCH = 4;
-template <int LPR>
+// YOUT = false: statistics only (p.y == NULL) — the (mean, rstd) rows a LayerNorm-folded GEMM reads (lvd_gemm_params.ln_mean_rstd)
+template <int LPR, bool YOUT = true>
 __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const lvd_ln_params p) {
   constexpr int RPW = 64 / LPR;  // rows per wave per batch
   const int lane = threadIdx.x & 63;
   const int r = lane / LPR, c = lane % LPR;
   const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * LN_BATCH);
-  float ga[5][8], be[5][8];
+  float ga[YOUT ? 5 : 1][8], be[YOUT ? 5 : 1][8];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < (YOUT ? 5 : 0); ++j) {
     const int ch = (c + j * LPR) * 8;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const lvd_ln_params p)
     if (row < p.rows) {
       if (c == 0 && p.mean_rstd) { p.mean_rstd[row * 2] = mean; p.mean_rstd[row * 2 + 1] = rstd; }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < (YOUT ? 5 : 0); ++j) {
         float v[8];
         unpack8(raw[j], v);
 #pragma unroll
@@ -653,14 +655,18 @@ extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void
 }
 
 extern "C" int lvdhip_layernorm(const lvd_ln_params* p, void* stream) {
-  LVD_CHECK(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
+  LVD_CHECK(p && p->x && ((p->y && p->gamma && p->beta) || p->mean_rstd), "layernorm: null pointer");  // y == NULL: statistics only
   LVD_CHECK(p->c % 8 == 0 && p->c <= 512 * LN_MAXV, "layernorm: c=%d unsupported (need c%%8==0, c<=%d)", p->c, 512 * LN_MAXV);
   hipStream_t s = (hipStream_t)stream;
   const int lpr = p->c % 40 == 0 ? p->c / 40 : 0;
   if (lpr == 8 || lpr == 16 || lpr == 32) {
     const int rows_per_block = 4 * (64 / lpr) * LN_BATCH;
     const dim3 grid((unsigned)((p->rows + rows_per_block - 1) / rows_per_block));
-    if (lpr == 8) hipLaunchKernelGGL(ln_fwd_rows_kernel<8>, grid, dim3(256), 0, s, *p);
+    if (!p->y) {
+      if (lpr == 8) hipLaunchKernelGGL((ln_fwd_rows_kernel<8, false>), grid, dim3(256), 0, s, *p);
+      else if (lpr == 16) hipLaunchKernelGGL((ln_fwd_rows_kernel<16, false>), grid, dim3(256), 0, s, *p);
+      else hipLaunchKernelGGL((ln_fwd_rows_kernel<32, false>), grid, dim3(256), 0, s, *p);
+    } else if (lpr == 8) hipLaunchKernelGGL(ln_fwd_rows_kernel<8>, grid, dim3(256), 0, s, *p);
     else if (lpr == 16) hipLaunchKernelGGL(ln_fwd_rows_kernel<16>, grid, dim3(256), 0, s, *p);
     else hipLaunchKernelGGL(ln_fwd_rows_kernel<32>, grid, dim3(256), 0, s, *p);
     LVD_LAUNCH_CHECK();

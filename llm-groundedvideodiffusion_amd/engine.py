@@ -84,6 +84,21 @@ class Geom:
         return self.B * self.F * self.H * self.W
 
 
+class LnRef:
+    """A LayerNorm that is never materialised: the rows x, their (mean, rstd) and the norm's parameter name.  The consuming linear
+    layers (to_qkv / to_q / ff.net.0.proj) run on x with the norm folded into the product (ops.gemm ln_stats=); `virt` stands in
+    for the normalised activation on the guidance tape (its gradient buffer is keyed by this object)."""
+
+    class _Virtual:
+        def __init__(self, shape, device):
+            self.shape, self.device = shape, device
+
+    def __init__(self, x, mr, name):
+        self.x, self.mr, self.name = x, mr, name
+        self.virt = LnRef._Virtual(tuple(x.shape), x.device)
+        self.shape = x.shape
+
+
 class TextCache:
     """Per cross-attention layer [B*77, 2C] key/value projections of the prompt embeddings."""
 
@@ -101,6 +116,10 @@ class HipUNet3D:
         self.w = {}
         self.alpha = {}
         self._dgrad = {}
+        # BasicTransformerBlock.norm1/2/3 folded into the products that consume them; LVD_LN_FOLD=0 restores the
+        # separate LayerNorm launches (A/B knob)
+        import os
+        self.ln_fold = os.environ.get("LVD_LN_FOLD", "1") != "0"
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -136,6 +155,21 @@ class HipUNet3D:
         for name in [n for n in list(w.keys()) if n.endswith(".ff.net.0.proj.weight")]:
             p = name[: -len(".weight")]
             w[p + ".weight"], w[p + ".bias"] = interleave_geglu(w[p + ".weight"], w[p + ".bias"])
+        # LayerNorm-folded copies of the products that read a transformer block's norm1/2/3: W' = gamma (.) W (bf16), colsum_n = sum_k W'_nk
+        # (of the ROUNDED W', so that a constant row cancels exactly), bias' = b + W beta.  The GLIGEN fuser keeps its materialised norms.
+        if self.ln_fold:
+            for name in [n for n in list(w.keys()) if n.endswith(".norm1.weight") and ".transformer_blocks." in n and ".fuser." not in n]:
+                blk = name[: -len(".norm1.weight")]
+                pairs = [("norm1", "attn1.to_qkv"), ("norm2", "attn2.to_qkv" if (blk + ".attn2.to_qkv.weight") in w else "attn2.to_q"),
+                         ("norm3", "ff.net.0.proj")]
+                for nrm, lin in pairs:
+                    W32 = w[f"{blk}.{lin}.weight"].float()
+                    gamma, beta = w[f"{blk}.{nrm}.weight"].float(), w[f"{blk}.{nrm}.bias"].float()
+                    Wp = (W32 * gamma[None, :]).to(torch.bfloat16).contiguous()
+                    b = w.get(f"{blk}.{lin}.bias")
+                    w[f"{blk}.{lin}.lnw"] = Wp
+                    w[f"{blk}.{lin}.lncolsum"] = Wp.float().sum(1).contiguous()
+                    w[f"{blk}.{lin}.lnbias"] = ((b.float() if b is not None else 0) + W32 @ beta).contiguous()
         self.cross_layers = sorted(n[: -len(".to_kv.weight")] for n in w if n.endswith(".to_kv.weight"))
         # the time-embedding projections of all ResnetBlock2Ds read the same [B, 1280] input: ONE product [B, sum of Cout] per forward
         # instead of 22 two-row GEMM launches; each conv1 reads its column range (lvd_gemm_params.ldrowbias)
@@ -184,9 +218,17 @@ class HipUNet3D:
 
     # ------------------------------------------------------------------ primitive ops with tape hooks
     def _linear(self, x, name, *, tape, res=None, bias=True, x2=None, alpha=1.0, act=ops.ACT_NONE, out_fp32=False):
-        W = self.w[name + ".weight"]
-        b = self.w.get(name + ".bias") if bias else None
-        out = ops.gemm(x, W, a2=x2, bias=b, res=res, alpha=alpha, act=act, out_fp32=out_fp32)
+        """x: token matrix, or an LnRef (the product then runs on the raw rows with the LayerNorm folded in)."""
+        ln = x if isinstance(x, LnRef) else None
+        if ln is not None:
+            assert x2 is None and not out_fp32 and res is None
+            out = ops.gemm(ln.x, self.w[name + ".lnw"], bias=self.w[name + ".lnbias"], alpha=alpha, act=act,
+                           ln_stats=ln.mr, ln_colsum=self.w[name + ".lncolsum"])
+            x = ln.virt  # the tape's handle of the (never written) normalised rows
+        else:
+            W = self.w[name + ".weight"]
+            b = self.w.get(name + ".bias") if bias else None
+            out = ops.gemm(x, W, a2=x2, bias=b, res=res, alpha=alpha, act=act, out_fp32=out_fp32)
         if tape is not None:
             assert act == ops.ACT_NONE and not out_fp32
 
@@ -194,7 +236,7 @@ class HipUNet3D:
                 dy = tape.pop(out)
                 if dy is None:
                     return
-                Wt = self.wt(name + ".weight")
+                Wt = self.wt(name + ".weight")  # d(LN out) = dy . W with the ORIGINAL W: the fold changes how the forward is computed, not what
                 if x2 is None:
                     buf, acc = tape.target(x)
                     ops.gemm(dy, Wt, out=buf, accumulate=acc, alpha=alpha)
@@ -299,8 +341,21 @@ class HipUNet3D:
             tape.push(bw)
         return out
 
-    def _layernorm(self, x, name, *, tape):
+    def _layernorm(self, x, name, *, tape, fold=False):
         gamma, beta = self.w[name + ".weight"], self.w[name + ".bias"]
+        if fold and self.ln_fold:
+            # statistics only; the consumers fold the norm into their products (LnRef).  The backward is the ordinary LayerNorm backward:
+            # it needs x, (mean, rstd) and the gradient of the normalised rows, which the consumers' dgrad GEMMs deliver under ref.virt.
+            ref = LnRef(x, ops.layernorm_stats(x), name)
+            if tape is not None:
+                def bw():
+                    dy = tape.pop(ref.virt)
+                    if dy is None:
+                        return
+                    buf, acc = tape.target(x)
+                    ops.layernorm_bwd(x, dy, gamma, ref.mr, dx=buf, accumulate=acc)
+                tape.push(bw)
+            return ref
         if tape is None:
             return ops.layernorm(x, gamma, beta)
         out, mr = ops.layernorm(x, gamma, beta, return_stats=True)
@@ -317,15 +372,20 @@ class HipUNet3D:
     def _self_attention(self, x, name, heads, *, samples, seq, rowmap, tape, x_extra=None, extra_map=None, seq_extra=0):
         """LN'd tokens -> fused QKV GEMM -> flash attention.  x_extra: second key/value segment (GLIGEN objs)."""
         C = heads * 64
-        qkv = ops.gemm(x, self.w[name + ".to_qkv.weight"])
+        ln = x if isinstance(x, LnRef) else None
+        if ln is not None:
+            qkv = ops.gemm(ln.x, self.w[name + ".to_qkv.lnw"], bias=self.w[name + ".to_qkv.lnbias"], ln_stats=ln.mr, ln_colsum=self.w[name + ".to_qkv.lncolsum"])
+            x = ln.virt
+        else:
+            qkv = ops.gemm(x, self.w[name + ".to_qkv.weight"])
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-        o = torch.empty((x.shape[0], C), dtype=torch.bfloat16, device=x.device)
+        o = torch.empty((x.shape[0], C), dtype=torch.bfloat16, device=qkv.device)
         kw = dict(samples=samples, heads=heads, sq=seq, skv=seq, qmap=rowmap, kvmap=rowmap, scale=0.125)
         if x_extra is not None:
             assert tape is None, "the guidance pass runs without GLIGEN conditioning (reference: models/pipelines.py:66-72)"
             qkv2 = ops.gemm(x_extra, self.w[name + ".to_qkv.weight"])
             kw.update(k2=qkv2[:, C:2 * C], v2=qkv2[:, 2 * C:], skv2=seq_extra, kv2map=extra_map)
-        lse = torch.empty((samples, heads, seq), dtype=torch.float32, device=x.device) if tape is not None else None
+        lse = torch.empty((samples, heads, seq), dtype=torch.float32, device=qkv.device) if tape is not None else None
         ops.attention_fwd(q, k, v, o, lse=lse, **kw)
         if tape is not None:
             def bw():
@@ -348,11 +408,11 @@ class HipUNet3D:
             collect["q"][key] = (q, k, heads, g)
             if key == collect.get("stop_after"):
                 raise StopForward()
-        o = torch.empty((x.shape[0], C), dtype=torch.bfloat16, device=x.device)
+        o = torch.empty((q.shape[0], C), dtype=torch.bfloat16, device=q.device)
         samples = g.B * g.F
         kw = dict(samples=samples, heads=heads, sq=g.HW, skv=text.ntext, qmap=ops.RowMap(1, g.HW, 0, 1),
                   kvmap=ops.RowMap(g.F, text.ntext, 0, 1), scale=0.125)
-        lse = torch.empty((samples, heads, g.HW), dtype=torch.float32, device=x.device) if tape is not None else None
+        lse = torch.empty((samples, heads, g.HW), dtype=torch.float32, device=q.device) if tape is not None else None
         ops.attention_fwd(q, k, v, o, lse=lse, **kw)
         if tape is not None:
             def bw():
@@ -390,18 +450,18 @@ class HipUNet3D:
             samples, seq, rmap = g.B * g.F, g.HW, ops.RowMap(1, g.HW, 0, 1)
         else:
             samples, seq, rmap = g.B * g.HW, g.F, ops.RowMap(g.HW, g.F * g.HW, 1, g.HW)
-        n1 = self._layernorm(hs, name + ".norm1", tape=tape)
+        n1 = self._layernorm(hs, name + ".norm1", tape=tape, fold=True)
         o = self._self_attention(n1, name + ".attn1", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
         hs = self._linear(o, name + ".attn1.to_out.0", tape=tape, res=hs)
         if objs is not None and (name + ".fuser.linear.weight") in self.w:
             hs = self._fuser(hs, name + ".fuser", heads, objs, g)
-        n2 = self._layernorm(hs, name + ".norm2", tape=tape)
+        n2 = self._layernorm(hs, name + ".norm2", tape=tape, fold=True)
         if spatial:
             o = self._cross_attention(n2, name + ".attn2", heads, text, g, tape=tape, key=key, collect=collect)
         else:
             o = self._self_attention(n2, name + ".attn2", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
         hs = self._linear(o, name + ".attn2.to_out.0", tape=tape, res=hs)
-        n3 = self._layernorm(hs, name + ".norm3", tape=tape)
+        n3 = self._layernorm(hs, name + ".norm3", tape=tape, fold=True)
         return self._feed_forward(n3, name + ".ff", hs, tape=tape)
 
     def _fuser(self, hs, name, heads, objs, g: Geom):

@@ -28,6 +28,7 @@ class GemmParams(C.Structure):
         ("frames", i32), ("hw", i32), ("rows_per_sample", i32), ("ldres", i32), ("ldc", i32),
         ("act", i32), ("out_fp32", i32), ("alpha", f32), ("accumulate", i32), ("variant", i32),
         ("ksplit", i32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("m_begin", i32), ("ldrowbias", i32),
+        ("ln_mean_rstd", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 

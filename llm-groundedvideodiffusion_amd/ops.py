@@ -135,6 +135,8 @@ def _tune_gemm(p, key, out):
     p.out, p.accumulate = scratch.data_ptr(), 0
     best, best_t = 0, float("inf")
     cands = GEMM_CANDIDATES + ((SPLITK_VARIANT, SPLITK_WIDE_VARIANT) + TAIL_VARIANTS if p.ws else ())
+    if p.ln_mean_rstd:  # LayerNorm-folded product: asm-DMA ring kernels and K-split plans only (include/lvdhip.h)
+        cands = tuple(v for v in cands if v >= 100 or v in (SPLITK_VARIANT, SPLITK_WIDE_VARIANT))
     halo = (p.mode == A_CONV3X3 and p.stride == 1 and p.win <= 87) or (p.mode == A_TCONV3 and 2 <= p.frames <= 256)
     if halo and not p.a2 and p.cin % 32 == 0:
         cands += (HALO_VARIANTS if p.ws else HALO_VARIANTS[:1])  # LDS-resident im2col (conv_halo.hip)
@@ -142,7 +144,10 @@ def _tune_gemm(p, key, out):
         if v in _EXCLUDE:
             continue
         p.variant = v
-        _launch_gemm(p)  # warm-up (also instruction-cache / L2)
+        try:
+            _launch_gemm(p)  # warm-up (also instruction-cache / L2)
+        except RuntimeError:
+            continue  # a plan this product cannot take (e.g. a K-split that degenerates to a kernel without the needed epilogue)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         evs[0].record()
         for i in range(5):
@@ -162,9 +167,13 @@ def _tune_gemm(p, key, out):
 
 def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sample=0, res=None, out=None,
          mode=A_PLAIN, conv: Optional[ConvGeom] = None, frames=0, hw=0, cin=None, act=ACT_NONE, out_fp32=False,
-         alpha=1.0, accumulate=False, m=None, variant=0, m_begin=0):
-    """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`.  `m_begin` > 0 produces rows [m_begin, M) only."""
+         alpha=1.0, accumulate=False, m=None, variant=0, m_begin=0, ln_stats=None, ln_colsum=None):
+    """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`.  `m_begin` > 0 produces rows [m_begin, M) only.
+    ln_stats ([M,2] fp32 mean/rstd from layernorm_stats) + ln_colsum ([N] fp32): LayerNorm(a1) · W^T with the norm folded into the product —
+    `w` must then be gamma (.) W and `bias` b + W beta (engine._pack builds them)."""
     _chk_bf16(a1, a2, w, res)
+    _chk_f32(ln_stats, ln_colsum)
+    assert (ln_stats is None) == (ln_colsum is None)
     _chk_f32(bias)
     _chk_f32_rows(rowbias)  # may be a column range of a wider matrix (engine: all temb projections of a forward are one product)
     N, K = w.shape if (n is None or k is None) else (n, k)
@@ -198,6 +207,9 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     p.ldc = _ld(out)
     p.act, p.out_fp32, p.alpha, p.accumulate = act, int(out_fp32), float(alpha), int(accumulate)
     p.m_begin = m_begin
+    if ln_stats is not None:
+        assert mode == A_PLAIN and a2 is None and ln_stats.shape == (m, 2) and ln_colsum.shape == (N,)
+        p.ln_mean_rstd, p.ln_colsum = _p(ln_stats), _p(ln_colsum)
     need = C.c_int64(0)
     hip.check(hip.lib().lvdhip_gemm_workspace_bytes(C.byref(p), C.byref(need)), "gemm_workspace_bytes")
     if need.value:
@@ -207,7 +219,7 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
         # everything a candidate's eligibility or cost depends on: the conv image (the LDS-resident tap GEMM needs W <= 87), the temporal
         # geometry (its tile is pixels x all frames) and a temb row-bias (the asm-DMA forms do not take one)
         key = (mode, m, N, K, act, c1, cin, (conv.stride, conv.upsample, conv.hin, conv.win) if conv is not None else None, int(out_fp32),
-               res is not None, bool(accumulate), frames, hw, rowbias is not None)
+               res is not None, bool(accumulate), frames, hw, rowbias is not None) + ((True,) if ln_stats is not None else ())
         variant = _gemm_choice.get(key) or 0
         if variant == 0 and not torch.cuda.is_current_stream_capturing():  # a capture replays what a warm-up run has tuned
             variant = _tune_gemm(p, key, out)
@@ -386,6 +398,18 @@ def layernorm(x, gamma, beta, *, eps=1e-5, out=None, return_stats=False):
     p.y, p.ldy, p.mean_rstd = _p(out), _ld(out), _p(mr)
     hip.check(hip.lib().lvdhip_layernorm(C.byref(p), _stream()), "layernorm")
     return (out, mr) if return_stats else out
+
+
+def layernorm_stats(x, *, eps=1e-5):
+    """(mean, rstd) [rows, 2] fp32 of every row — what a LayerNorm-folded GEMM (gemm(..., ln_stats=)) and layernorm_bwd read; x is only read."""
+    _chk_bf16(x)
+    rows, c = x.shape
+    mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    p = hip.LnParams()
+    p.x, p.ldx, p.rows, p.c, p.gamma, p.beta, p.eps = _p(x), _ld(x), rows, c, None, None, eps
+    p.y, p.ldy, p.mean_rstd = None, 0, _p(mr)
+    hip.check(hip.lib().lvdhip_layernorm(C.byref(p), _stream()), "layernorm_stats")
+    return mr
 
 
 def layernorm_bwd(x, dy, gamma, mean_rstd, *, dx=None, accumulate=False):

@@ -394,6 +394,64 @@ def test_gemm_many_tiles(variant):
     close(from_tokens(out, n, h, wd), refc, 6e-3, f"v{variant} many-tiles conv")
 
 
+def _ln_fold_operands(W, bias, gamma, beta):
+    """What engine._pack prepares for a LayerNorm-folded product: W' = gamma (.) W (bf16), colsum of the ROUNDED W', bias' = b + W beta."""
+    Wp = bf(W.float() * gamma[None, :])
+    return Wp, Wp.float().sum(1).contiguous(), ((bias if bias is not None else 0) + W.float() @ beta).contiguous()
+
+
+@pytest.mark.parametrize("variant", [0, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231, 20, 25])
+@pytest.mark.parametrize("M,N,K", [(700, 320, 320), (3000, 960, 640), (513, 2560, 320)])
+def test_gemm_layernorm_fold(variant, M, N, K):
+    """LayerNorm(x) W^T + b as ONE product on the raw rows (lvd_gemm_params.ln_mean_rstd): every asm-DMA ring geometry and the K-split
+    plans against the fp32 reference  F.layer_norm(x) @ W^T + b;  rows with a large common offset (|mean| = 8 sigma) exercise the
+    cancellation  x.W' - mean * colsum.  Tolerance: bf16 output rounding plus the bf16 rounding of gamma (.) W."""
+    x = rnd(M, K, seed=1)
+    x[::3] += 8.0  # a third of the rows sit far from zero
+    x = bf(x)
+    W, bias = bf(rnd(N, K, seed=2, scale=0.05)), rnd(N, seed=3)
+    gamma, beta = 1.0 + 0.3 * rnd(K, seed=4), 0.2 * rnd(K, seed=5)
+    ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.float().T + bias
+    Wp, colsum, bp = _ln_fold_operands(W, bias, gamma, beta)
+    mr = ops.layernorm_stats(x)
+    xf = x.float()
+    assert torch.allclose(mr[:, 0], xf.mean(1), atol=1e-3) and torch.allclose(mr[:, 1], (xf.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3)
+    try:
+        out = ops.gemm(x, Wp, bias=bp, ln_stats=mr, ln_colsum=colsum, variant=variant)
+    except RuntimeError as e:
+        # a K-split plan that decides not to split (short K, well-filled grid) degenerates to the builtin-DMA ring, which has no folded
+        # epilogue: an error the autotuner skips over, never a silently un-normalised product
+        assert variant in (20, 25) and "LayerNorm-folded" in str(e), e
+        return
+    close(out, ref, 8e-3, f"v{variant} layernorm fold")
+    # the folded product equals the two-launch path (LayerNorm kernel, then the plain product) to bf16 rounding
+    two = ops.gemm(ops.layernorm(x, gamma, beta), W, bias=bias, variant=variant)
+    close(out, two, 1.2e-2, f"v{variant} fold vs LayerNorm + GEMM")
+
+
+@pytest.mark.parametrize("variant", [0, 105, 111, 211])
+def test_gemm_layernorm_fold_geglu(variant):
+    from lvd_amd.weights import interleave_geglu
+    M, K, H = 900, 320, 1280
+    x = bf(rnd(M, K, seed=1) + 2.0)
+    W, bias = bf(rnd(2 * H, K, seed=2, scale=0.05)), rnd(2 * H, seed=3)
+    gamma, beta = 1.0 + 0.3 * rnd(K, seed=4), 0.2 * rnd(K, seed=5)
+    proj = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.float().T + bias
+    ref = proj[:, :H] * F.gelu(proj[:, H:])
+    wi, bi = interleave_geglu(W, bias)
+    Wp, colsum, bp = _ln_fold_operands(wi, bi, gamma, beta)
+    out = ops.gemm(x, Wp, bias=bp, act=ops.ACT_GEGLU, ln_stats=ops.layernorm_stats(x), ln_colsum=colsum, variant=variant)
+    close(out, ref, 1e-2, f"v{variant} layernorm fold + GEGLU")
+
+
+def test_gemm_layernorm_fold_rejects_kernels_without_it():
+    x, W = bf(rnd(256, 320, seed=1)), bf(rnd(320, 320, seed=2, scale=0.05))
+    mr, cs = ops.layernorm_stats(x), W.float().sum(1).contiguous()
+    for v in (1, 10, 5, 11):  # register-staged / builtin-DMA kernels have no folded epilogue: an error, not a silently un-normalised product
+        with pytest.raises(RuntimeError, match="LayerNorm-folded"):
+            ops.gemm(x, W, ln_stats=mr, ln_colsum=cs, variant=v)
+
+
 @pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
