@@ -15,6 +15,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "load":
     gam, bet = torch.ones(64, device=dev), torch.zeros(64, device=dev)
     g5, b5 = torch.ones(512, device=dev), torch.zeros(512, device=dev)
     w = (torch.randn(512, 64, device=dev, generator=g) * 0.05).bfloat16()
+    ops.groupnorm(x, gam, bet, 2880, groups=32, silu=True)
+    torch.cuda.synchronize()
+    print("READY", flush=True)  # the first launch has run: a parent that waits for this line measures next to a live co-tenant
     t0 = time.time()
     while time.time() - t0 < float(sys.argv[2]):
         for _ in range(20):

@@ -607,20 +607,26 @@ def test_gemm_split_k(SPLITK):
     close(out, reft, 6e-3, f"v{SPLITK} split-K tconv")
 
 
+def _start_cotenant(seconds):
+    """A second process that loops over GroupNorm / LayerNorm / small GEMM / SiLU launches on this GPU; returns once its first launch
+    has run (it prints READY), i.e. what follows is measured next to a live co-tenant — no fixed sleep."""
+    import os
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "gemm_cotenant_probe.py")
+    load = subprocess.Popen([sys.executable, probe, "load", str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    line = load.stdout.readline()  # blocks until the probe is up (or has died: empty string)
+    assert line.strip() == "READY" and load.poll() is None, f"the co-tenant process did not come up: {line!r}"
+    return load
+
+
 def test_gemm_bit_reproducible_next_to_a_cotenant_process():
     """Regression test of the round-3 race: the first 64-deep ring refilled an LDS slot that sibling waves of the same group were still
     reading.  Alone on the GPU the refill always landed after those reads and every test passed; next to a SECOND PROCESS whose small
     workgroups share the CUs (other launch timing, other workgroup placement) 8-25 of 25 launches came out with up to 4 000 wrong elements.
     Every hand-synchronised GEMM variant must give the same bits on every launch while such a co-tenant runs."""
-    import os
-    import subprocess
-    import sys
-    import time
-    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "gemm_cotenant_probe.py")
-    load = subprocess.Popen([sys.executable, probe, "load", "60"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    load = _start_cotenant(60)
     try:
-        time.sleep(8)  # the co-tenant has built its tensors and loops over GroupNorm / LayerNorm / small GEMM / SiLU launches
-        assert load.poll() is None, "the co-tenant process died"
         M, N, K = 69120, 1536, 512
         a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
         bias = rnd(N, seed=3)
@@ -634,6 +640,74 @@ def test_gemm_bit_reproducible_next_to_a_cotenant_process():
             ref = ops.gemm(x, wt, mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=v)
             for rep in range(8):
                 assert torch.equal(ops.gemm(x, wt, mode=ops.A_CONV3X3, conv=ops.ConvGeom(h, wd, h, wd), variant=v), ref), f"conv variant {v}: launch {rep} differs"
+    finally:
+        load.terminate()
+        load.wait(timeout=30)
+
+
+def test_every_hand_synchronised_kernel_is_bit_reproducible_next_to_a_cotenant_process():
+    """The same screen for every other kernel family that orders LDS traffic by hand (counted vmcnt / lgkmcnt waits, raw s_barrier,
+    double-buffered LDS tiles): the tap GEMMs as temporal convs (conv_halo.hip, variants 41 / 45 / 47), the 4-wave flash-attention forward
+    and backward (attn_fwd_v2, attn_bwd_dq_v2 / dkv_v2), the one-wave kernels incl. the one-pass temporal backward (attn_bwd_small), the
+    LayerNorm-folded ring kernels, and the GroupNorm passes whose apply kernels fold the statistics partials themselves.  20 launches
+    each, every output bit-equal to the first."""
+    from lvd_amd.weights import pack_tconv3
+    load = _start_cotenant(90)
+    REPS = 20
+
+    def same(name, fn):
+        ref = [t.clone() for t in fn()]
+        for rep in range(REPS):
+            out = fn()
+            assert all(torch.equal(a, b) for a, b in zip(out, ref)), f"{name}: launch {rep} differs from the first one"
+
+    try:
+        B, Fr, h, wd, C = 2, 24, 20, 36, 128
+        rows = B * Fr * h * wd
+        x, res = bf(rnd(rows, C, seed=1)), bf(rnd(rows, C, seed=2))
+        wt = pack_tconv3(rnd(C, C, 3, 1, 1, seed=3, scale=0.05)).to(DEV)
+        bias = rnd(C, seed=4)
+        for v in (41, 45, 47):
+            same(f"tconv v{v}", lambda: (ops.gemm(x, wt, bias=bias, res=res, mode=ops.A_TCONV3, frames=Fr, hw=h * wd, variant=v),))
+        heads = C // 64
+        q, k, v_ = bf(rnd(rows, C, seed=5)), bf(rnd(rows, C, seed=6)), bf(rnd(rows, C, seed=7))
+        do = bf(rnd(rows, C, seed=8))
+        for nm, samples, seq, rmap in (("spatial", B * Fr, h * wd, ops.RowMap(1, h * wd, 0, 1)),
+                                       ("temporal", B * h * wd, Fr, ops.RowMap(h * wd, Fr * h * wd, 1, h * wd))):
+            kw = dict(samples=samples, heads=heads, sq=seq, skv=seq, qmap=rmap, kvmap=rmap, scale=0.125)
+            o, lse = torch.empty_like(q), torch.empty(samples, heads, seq, device=DEV)
+
+            def fwd():
+                oo, ll = torch.empty_like(q), torch.empty_like(lse)
+                ops.attention_fwd(q, k, v_, oo, lse=ll, **kw)
+                return oo, ll
+            same(f"attention_fwd {nm}", fwd)
+            ops.attention_fwd(q, k, v_, o, lse=lse, **kw)
+
+            def bwd():
+                dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+                ops.attention_bwd(q, k, v_, o, lse, do, dq, dk, dv, **kw)
+                return dq, dk, dv
+            same(f"attention_bwd {nm}", bwd)
+        kt, vt = bf(rnd(B * 77, C, seed=9)), bf(rnd(B * 77, C, seed=10))
+        kwc = dict(samples=B * Fr, heads=heads, sq=h * wd, skv=77, qmap=ops.RowMap(1, h * wd, 0, 1), kvmap=ops.RowMap(Fr, 77, 0, 1), scale=0.125)
+        same("attention_fwd text cross", lambda: (ops.attention_fwd(q, kt, vt, torch.empty_like(q), **kwc),))
+        # LayerNorm-folded products (their own ring instantiations) and the statistics launch
+        Kc, N = 320, 960
+        xa = bf(rnd(69120, Kc, seed=11))
+        W = bf(rnd(N, Kc, seed=12, scale=0.05))
+        gamma, beta = 1.0 + 0.3 * rnd(Kc, seed=13), 0.2 * rnd(Kc, seed=14)
+        Wp, colsum, bp = _ln_fold_operands(W, None, gamma, beta)
+        same("layernorm_stats", lambda: (ops.layernorm_stats(xa),))
+        mr = ops.layernorm_stats(xa)
+        for v in (105, 109, 111, 117, 211, 231):
+            same(f"layernorm-folded gemm v{v}", lambda: (ops.gemm(xa, Wp, bias=bp, ln_stats=mr, ln_colsum=colsum, variant=v),))
+        # GroupNorm: statistics partials + the apply kernels that fold them (2-D and 5-D sample sizes), forward and backward
+        gam, bet = 1 + 0.1 * rnd(C, seed=15), 0.1 * rnd(C, seed=16)
+        for nm, rps in (("2d", h * wd), ("5d", Fr * h * wd)):
+            same(f"groupnorm {nm}", lambda: ops.groupnorm_auto(x, gam, bet, rps, silu=True))
+            _, mrg = ops.groupnorm_auto(x, gam, bet, rps, silu=True)
+            same(f"groupnorm_bwd {nm}", lambda: (ops.groupnorm_bwd(x, do, gam, bet, mrg, rps, silu=True)[0],))
     finally:
         load.terminate()
         load.wait(timeout=30)
