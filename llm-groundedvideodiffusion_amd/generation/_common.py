@@ -86,51 +86,80 @@ class Method:
             attn_sync_weight=0.0, boxdiff_loss_scale=0.0, boxdiff_normed=True, com_loss_scale=0.0, use_ratio_based_loss=False,
             save_formats=("gif", "joblib"), gligen_scheduled_sampling_beta=None, prompt_embeds=None, negative_prompt_embeds=None,
             gligen_phrase_embeds=None, latents=None):
+        """One video (the reference's `run`, generation/lvd.py:79-210): the V = 1 case of `run_many`."""
+        job = dict(parsed_layout=parsed_layout, seed=seed, repeat_ind=repeat_ind, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
+                   gligen_phrase_embeds=gligen_phrase_embeds, latents=latents)
+        return self.run_many([job], num_inference_steps=num_inference_steps, num_frames=num_frames, save_annotated_videos=save_annotated_videos,
+                             loss_scale=loss_scale, loss_threshold=loss_threshold, max_iter=max_iter, max_index_step=max_index_step, fg_top_p=fg_top_p,
+                             bg_top_p=bg_top_p, fg_weight=fg_weight, bg_weight=bg_weight, attn_sync_weight=attn_sync_weight,
+                             boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed, com_loss_scale=com_loss_scale,
+                             use_ratio_based_loss=use_ratio_based_loss, save_formats=save_formats,
+                             gligen_scheduled_sampling_beta=gligen_scheduled_sampling_beta)[0]
+
+    def run_many(self, jobs, num_inference_steps=40, num_frames=16, save_annotated_videos=False, loss_scale=5.0, loss_threshold=200.0, max_iter=5,
+                 max_index_step=10, fg_top_p=0.75, bg_top_p=0.75, fg_weight=1.0, bg_weight=4.0, attn_sync_weight=0.0, boxdiff_loss_scale=0.0,
+                 boxdiff_normed=True, com_loss_scale=0.0, use_ratio_based_loss=False, save_formats=("gif", "joblib"),
+                 gligen_scheduled_sampling_beta=None):
+        """V independent (layout, seed) samples through ONE denoising loop (pipeline.sample_many: per-sample guidance passes, one CFG forward
+        of batch 2V per step) — generate.py --videos-per-gpu V.  `jobs`: dicts with parsed_layout, seed and optionally repeat_ind, img_dir
+        (default: the configured one), prompt_embeds, negative_prompt_embeds, gligen_phrase_embeds, latents.  The seed rule, the file names and
+        the skip-if-exists behaviour are those of `run`; returns one entry per job (frames, latents, or None for a skipped job)."""
         pipe = self.pipe
         if pipe is None:
             raise RuntimeError("call init(base_model) first")
         H, W = self.base["H"], self.base["W"]
         box_h, box_w = dsl.LAYOUT_SIZE
-        cond = dsl.layout_to_condition(parsed_layout, height=box_h, width=box_w, num_condition_frames=num_frames, tokenizer=pipe.tokenizer)
-        if self.use_guidance and cond.object_positions is None:
-            raise RuntimeError("attention guidance needs object token positions: inject a tokenizer (configure(tokenizer=...))")
-        img_dir = _components["img_dir"]
-        suffix = repeat_ind if repeat_ind is not None else f"seed{seed}"
-        save_path = f"{img_dir}/video_{suffix}.gif"
-        if os.path.exists(save_path):
-            print(f"Skipping {save_path}")
-            return None
+        want_latent = pipe.vae is None
+        results, todo, samples = [None] * len(jobs), [], []
+        for n, job in enumerate(jobs):
+            cond = dsl.layout_to_condition(job["parsed_layout"], height=box_h, width=box_w, num_condition_frames=num_frames, tokenizer=pipe.tokenizer)
+            if self.use_guidance and cond.object_positions is None:
+                raise RuntimeError("attention guidance needs object token positions: inject a tokenizer (configure(tokenizer=...))")
+            img_dir = job.get("img_dir") or _components["img_dir"]
+            repeat_ind, seed = job.get("repeat_ind"), job["seed"]
+            suffix = repeat_ind if repeat_ind is not None else f"seed{seed}"
+            if os.path.exists(f"{img_dir}/video_{suffix}.gif"):
+                print(f"Skipping {img_dir}/video_{suffix}.gif")
+                continue
+            smp = {}
+            if self.use_guidance:
+                smp["backward_guidance_kwargs"] = dict(
+                    bboxes=cond.boxes, object_positions=cond.object_positions, loss_scale=loss_scale, loss_threshold=loss_threshold,
+                    max_iter=max_iter, max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
+                    bg_weight=bg_weight, use_ratio_based_loss=use_ratio_based_loss, guidance_attn_keys=GUIDANCE_ATTN_KEYS,
+                    exclude_bg_heads=False, upsample_scale=1, upsample_mode="bilinear", base_attn_dim=self.base["base_attn_dim"],
+                    attn_sync_weight=attn_sync_weight, boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed,
+                    com_loss_scale=com_loss_scale, verbose=False)
+            if self.use_gligen:
+                absent = [0.0, 0.0, 0.0, 0.0]
+                smp["gligen_boxes"] = [[b[i] for b in cond.boxes if b[i] != absent] for i in range(num_frames)]
+                smp["gligen_phrases"] = [[p for p, b in zip(cond.phrases, cond.boxes) if b[i] != absent] for i in range(num_frames)]
+                smp["gligen_phrase_embeds"] = job.get("gligen_phrase_embeds")
+            pe = job.get("prompt_embeds")
+            smp.update(prompt=cond.prompt if pe is None else None, negative_prompt=dsl.NEGATIVE_PROMPT if pe is None else None, prompt_embeds=pe,
+                       negative_prompt_embeds=job.get("negative_prompt_embeds"), latents=job.get("latents"),
+                       generator=torch.Generator(device="cpu").manual_seed(int(seed)))  # CPU generator: reproducible across devices (SURVEY §7 RNG note)
+            todo.append((n, cond, img_dir, suffix))
+            samples.append(smp)
+        if not samples:
+            return results
         kw = {}
         if self.use_guidance:
-            kw["backward_guidance_kwargs"] = dict(
-                bboxes=cond.boxes, object_positions=cond.object_positions, loss_scale=loss_scale, loss_threshold=loss_threshold,
-                max_iter=max_iter, max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
-                bg_weight=bg_weight, use_ratio_based_loss=use_ratio_based_loss, guidance_attn_keys=GUIDANCE_ATTN_KEYS,
-                exclude_bg_heads=False, upsample_scale=1, upsample_mode="bilinear", base_attn_dim=self.base["base_attn_dim"],
-                attn_sync_weight=attn_sync_weight, boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed,
-                com_loss_scale=com_loss_scale, verbose=False)
-            kw["custom_latent_backward_guidance"] = hip_latent_backward_guidance
-            kw["guidance_type"] = "main"
+            kw.update(custom_latent_backward_guidance=hip_latent_backward_guidance, guidance_type="main")
         if self.use_gligen:
-            absent = [0.0, 0.0, 0.0, 0.0]
-            kw["gligen_boxes"] = [[b[i] for b in cond.boxes if b[i] != absent] for i in range(num_frames)]
-            kw["gligen_phrases"] = [[p for p, b in zip(cond.phrases, cond.boxes) if b[i] != absent] for i in range(num_frames)]
             kw["gligen_scheduled_sampling_beta"] = 1.0 if gligen_scheduled_sampling_beta is None else gligen_scheduled_sampling_beta
-            kw["gligen_phrase_embeds"] = gligen_phrase_embeds
-        gen = torch.Generator(device="cpu").manual_seed(int(seed))  # CPU generator: reproducible across devices (SURVEY §7 RNG note)
-        want_latent = pipe.vae is None
-        out = pipe(cond.prompt if prompt_embeds is None else None, negative_prompt=dsl.NEGATIVE_PROMPT if prompt_embeds is None else None,
-                   num_inference_steps=num_inference_steps, height=H, width=W, num_frames=num_frames,
-                   cross_attention_kwargs={"save_attn_to_dict": {}, "save_keys": []}, generator=gen, latents=latents,
-                   prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
-                   output_type="latent" if want_latent else "np", **kw).frames
-        os.makedirs(img_dir, exist_ok=True)
-        if want_latent:
-            import joblib
-            joblib.dump(out.float().cpu().numpy(), f"{img_dir}/latents_{suffix}.joblib", compress=("bz2", 3))
-            return out
-        frames = (np.asarray(out[0]) * 255.0).astype(np.uint8)  # uint8 (F,H,W,3), also for the gligen method
-        if save_annotated_videos:  # the reference builds this path under the .gif name (generation/lvd.py:188-189); a sibling file here
-            vis.save_frames(f"{img_dir}/video_{suffix}_with_box", vis.draw_boxes(frames, cond.boxes, cond.phrases), formats="gif")
-        vis.save_frames(f"{img_dir}/video_{suffix}", frames, formats=list(save_formats))
-        return frames
+        outs = pipe.sample_many(samples, num_inference_steps=num_inference_steps, height=H, width=W, num_frames=num_frames,
+                                cross_attention_kwargs={"save_attn_to_dict": {}, "save_keys": []}, output_type="latent" if want_latent else "np", **kw)
+        for (n, cond, img_dir, suffix), out in zip(todo, outs):
+            os.makedirs(img_dir, exist_ok=True)
+            if want_latent:
+                import joblib
+                joblib.dump(out.float().cpu().numpy(), f"{img_dir}/latents_{suffix}.joblib", compress=("bz2", 3))
+                results[n] = out
+                continue
+            frames = (np.asarray(out[0]) * 255.0).astype(np.uint8)  # uint8 (F,H,W,3), also for the gligen method (SURVEY B.2)
+            if save_annotated_videos:  # the reference builds this path under the .gif name (generation/lvd.py:188-189); a sibling file here
+                vis.save_frames(f"{img_dir}/video_{suffix}_with_box", vis.draw_boxes(frames, cond.boxes, cond.phrases), formats="gif")
+            vis.save_frames(f"{img_dir}/video_{suffix}", frames, formats=list(save_formats))
+            results[n] = frames
+        return results

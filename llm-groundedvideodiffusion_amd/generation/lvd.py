@@ -12,3 +12,8 @@ def init(base_model):
 
 def run(parsed_layout, seed, **kwargs):
     return _m.run(parsed_layout, seed, **kwargs)
+
+
+def run_many(jobs, **kwargs):
+    """V (layout, seed) samples through one denoising loop (generate.py --videos-per-gpu V; _common.Method.run_many)."""
+    return _m.run_many(jobs, **kwargs)

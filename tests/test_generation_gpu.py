@@ -159,6 +159,38 @@ def test_generate_cli_resume_and_seed_rule(tmp_path, monkeypatch):
         generate.main([a if a != "24" else "16" for a in argv])  # zeroscope with < 24 frames is refused like in the reference
 
 
+def test_generate_videos_per_gpu_batches_jobs_and_keeps_seeds_and_files(tmp_path):
+    """generate.py --videos-per-gpu 2 (throughput mode, reference loop generate.py:325-338 batched): the two repeats of a prompt go through
+    ONE denoising loop (their CFG forwards as one batch-4 pass, guidance per sample).  Same seed rule and file names as the one-video-at-a-
+    time run; the videos agree with it to the bf16 rounding of tile geometries chosen for another M (stated bound: PSNR >= 40 dB on the
+    8-bit frames; bit-equal whenever the same geometries are picked)."""
+    import generate
+    demo = [c for c in CASES if c["cache"].startswith("cache_demo")][0]
+    cache_dir = tmp_path / "cache"
+    cache_dir.mkdir()
+    (cache_dir / "cache_demo_v0.1_gpt-4-1106-preview.json").write_text(json.dumps({demo["prompt"]: [demo["response"]]}))
+    _configure(tmp_path, gated=False)
+
+    def argv(out, v):
+        return ["--model", "gpt-4", "--run-model", "lvd_zeroscope", "--prompt-type", "demo", "--template_version", "v0.1", "--num_frames", "24",
+                "--num_inference_steps", "4", "--max_index_step", "2", "--max_iter", "1", "--repeats", "3", "--seed_offset", "7", "--force_run_ind", "0",
+                "--cache-dir", str(cache_dir), "--img-root", str(tmp_path / out), "--videos-per-gpu", str(v)]
+    assert generate.main(argv("one", 1)) == 3
+    assert generate.main(argv("two", 2)) == 3  # a batch of two and a last batch of one
+    sub = os.path.join("imgs_demo_templatev0.1_lvd_zeroscope", "run0", "0")
+    worst = 1e9
+    for r in range(3):
+        a = joblib.load(tmp_path / "one" / sub / f"video_{r}.joblib").astype(np.float64)
+        b = joblib.load(tmp_path / "two" / sub / f"video_{r}.joblib").astype(np.float64)
+        assert a.shape == b.shape == (24, 320, 576, 3)
+        mse = float(((a - b) ** 2).mean())
+        psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+        worst = min(worst, psnr)
+    print("videos-per-gpu 2 vs 1: worst PSNR over 3 seeds", worst)
+    assert worst >= 40.0, worst
+    assert generate.main(argv("two", 2)) == 0  # resumed: everything exists
+
+
 _DRIVER = '''
 import sys
 sys.path.insert(0, {repo!r})
