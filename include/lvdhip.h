@@ -320,6 +320,13 @@ typedef struct {
   float* acc32; int32_t ldacc; int32_t acc_mode;
 } lvd_ca_dq_params;
 int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream);
+/* All keys of one guidance iteration (utils/guidance.py:529-574 loops over guidance_attn_keys) in ONE launch per stage instead of one per
+ * key: `keys` is a host array of `nkeys` <= LVD_CA_MAX_KEYS parameter blocks, each exactly what the single-key entry point takes (its own
+ * q / k / P / heads / buffers); blockIdx.z selects the key.  Same results, bit for bit, as nkeys single-key calls. */
+#define LVD_CA_MAX_KEYS 8
+int lvdhip_ca_probs_multi(const lvd_ca_probs_params* keys, int32_t nkeys, void* stream);
+int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t nkeys, void* stream);
+int lvdhip_ca_dq_multi(const lvd_ca_dq_params* keys, int32_t nkeys, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise / layout kernels.

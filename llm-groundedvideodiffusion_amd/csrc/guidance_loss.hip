@@ -13,6 +13,7 @@
 //   3. ca_dq     : softmax backward over the 77 keys (only the token columns carry gradient) and
 //                  dQ = scale · dS · K with K^T staged through LDS — HBM traffic = read Q + write dQ.
 // All loss arithmetic is fp32 (the reference's mask is fp32, so A·mask promotes: utils/guidance.py:239,339-353).
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -47,10 +48,10 @@ LVD_DEV float dot8(uint4 a, uint4 b) {
 
 // ------------------------------------------------------------------------------------ 1. probs
 // grid (frames * ceil(P/32), heads), one wave per 32-query tile
-__global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params p) {
+LVD_DEV void ca_probs_body(const lvd_ca_probs_params& p, const int bx, const int by) {
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
   const int nqt = (p.P + 31) >> 5;
-  const int f = blockIdx.x / nqt, qt = blockIdx.x - f * nqt, h = blockIdx.y;
+  const int f = bx / nqt, qt = bx - f * nqt, h = by;
   const int qi = qt * 32 + l31;
   const int qic = min(qi, p.P - 1);
   const lvd_bf16* qp = p.q + ((long)f * p.P + qic) * p.ldq + h * 64 + hi * 8;
@@ -98,9 +99,8 @@ __global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params 
 
 // ------------------------------------------------------------------------------------ 2a. centre of mass
 // grid frames*heads*ntok, block 256: com_ws[.,4] = (sum A, com_y, com_x, 0)
-__global__ void ca_com_kernel(const lvd_ca_select_params p) {
+LVD_DEV void ca_com_body(const lvd_ca_select_params& p, const int b) {
   __shared__ float red[3][4];
-  const int b = blockIdx.x;
   const float* A = p.probs + (long)b * p.P;
   float s = 0.f, sy = 0.f, sx = 0.f;
   for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
@@ -181,7 +181,7 @@ LVD_DEV void radix_select2(const float* vals, const unsigned char* flag, int n, 
   thr[1] = on1 ? prefix[1] : ~0ull;
 }
 
-__global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_params p) {
+LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
   extern __shared__ unsigned char smem[];
   float* vals = reinterpret_cast<float*>(smem);                         // [P]
   unsigned char* flag = smem + (size_t)p.P * 4;                         // [P] 1 = inside the box
@@ -190,7 +190,6 @@ __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_para
   __shared__ int wtot[2][4];
   __shared__ float red[8];
 
-  const int b = blockIdx.x;
   const int t = b % p.ntok;
   const int fh = b / p.ntok;
   const int h = fh % p.heads, f = fh / p.heads;
@@ -363,11 +362,11 @@ __global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_para
 // NT = compile-time bound on the object tokens of the launch (2 / 4 / 8 / 16): the per-score test "is this key one of the object tokens"
 // costs 16 x NT selects per key tile, and with the bound fixed at 16 it was the kernel (768 VALU operations per tile against 8 MFMAs).
 template <int NT>
-__global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
+LVD_DEV void ca_dq_body(const lvd_ca_dq_params& p, const int bx, const int by) {
   __shared__ uint32_t kt_lds[64 * TP];
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
   const int nqt = (p.P + 31) >> 5;
-  const int f = blockIdx.x / nqt, qt = blockIdx.x - f * nqt, h = blockIdx.y;
+  const int f = bx / nqt, qt = bx - f * nqt, h = by;
   const int qi = qt * 32 + l31;
   const int qic = min(qi, p.P - 1);
   const lvd_bf16* qp = p.q + ((long)f * p.P + qic) * p.ldq + h * 64 + hi * 8;
@@ -462,12 +461,130 @@ __global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ kernels: one key, or all keys of an iteration
+// The six guidance keys of an iteration are independent and small (180-720 query positions x 10-20 heads): launched one by one they are
+// 18 launches of latency-bound one-wave workgroups.  The *_multi kernels take the per-key parameter blocks as ONE kernel argument and
+// blockIdx.z picks the key; a block outside its key's own grid leaves at once (the grid is the largest key's).
+template <class P>
+struct KeyTable {
+  P k[LVD_CA_MAX_KEYS];
+};
+LVD_DEV int probs_gx(const lvd_ca_probs_params& p) { return ((p.P + 31) >> 5) * p.frames; }
+LVD_DEV int dq_gx(const lvd_ca_dq_params& p) { return ((p.P + 31) >> 5) * p.frames; }
+
+__global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params p) { ca_probs_body(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void ca_probs_multi_kernel(const KeyTable<lvd_ca_probs_params> tab) {
+  const lvd_ca_probs_params& p = tab.k[blockIdx.z];
+  if ((int)blockIdx.x >= probs_gx(p) || (int)blockIdx.y >= p.heads) return;
+  ca_probs_body(p, blockIdx.x, blockIdx.y);
+}
+__global__ void ca_com_kernel(const lvd_ca_select_params p) { ca_com_body(p, blockIdx.x); }
+__global__ void ca_com_multi_kernel(const KeyTable<lvd_ca_select_params> tab) {
+  const lvd_ca_select_params& p = tab.k[blockIdx.y];
+  if ((int)blockIdx.x >= p.frames * p.heads * p.ntok) return;
+  ca_com_body(p, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_params p) { ca_select_body(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void ca_select_multi_kernel(const KeyTable<lvd_ca_select_params> tab) {
+  const lvd_ca_select_params& p = tab.k[blockIdx.y];
+  if ((int)blockIdx.x >= p.frames * p.heads * p.ntok) return;
+  ca_select_body(p, blockIdx.x);
+}
+template <int NT>
+__global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) { ca_dq_body<NT>(p, blockIdx.x, blockIdx.y); }
+template <int NT>
+__global__ __launch_bounds__(64) void ca_dq_multi_kernel(const KeyTable<lvd_ca_dq_params> tab) {
+  const lvd_ca_dq_params& p = tab.k[blockIdx.z];
+  if ((int)blockIdx.x >= dq_gx(p) || (int)blockIdx.y >= p.heads) return;
+  ca_dq_body<NT>(p, blockIdx.x, blockIdx.y);
+}
+
 }  // namespace
 
-extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) {
+namespace {
+int check_probs(const lvd_ca_probs_params* p) {
   LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->lse, "ca_probs: null pointer");
   LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_probs: ntok=%d outside 1..%d", p->ntok, MAXTOK);
   LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0, "ca_probs: leading dims");
+  return 0;
+}
+int check_select(const lvd_ca_select_params* p) {
+  LVD_CHECK(p && p->probs && p->dprobs && p->tok_obj && p->boxes && p->tok_weight && p->loss_partial && p->com_ws, "ca_select: null pointer");
+  LVD_CHECK(p->P == p->H * p->W && p->P <= 4096, "ca_select: P=%d must equal H*W and be <= 4096", p->P);
+  return 0;
+}
+int check_dq(const lvd_ca_dq_params* p) {
+  LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->dprobs && p->lse && p->dq, "ca_dq: null pointer");
+  LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_dq: ntok=%d outside 1..%d", p->ntok, MAXTOK);
+  LVD_CHECK(p->acc_mode >= 0 && p->acc_mode <= 3 && (p->acc_mode == 0 || (p->acc32 && p->ldacc % 4 == 0)), "ca_dq: acc_mode %d needs an fp32 accumulator", p->acc_mode);
+  return 0;
+}
+}  // namespace
+
+// All keys of a guidance iteration in one launch each (3 launches instead of 3 per key; 4 with the centre-of-mass term).  `keys` is a
+// host array of `nkeys` (<= LVD_CA_MAX_KEYS) parameter blocks, each exactly what the single-key entry point takes.
+extern "C" int lvdhip_ca_probs_multi(const lvd_ca_probs_params* keys, int32_t nkeys, void* stream) {
+  LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_probs_multi: 1..%d keys", LVD_CA_MAX_KEYS);
+  KeyTable<lvd_ca_probs_params> tab;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < nkeys; ++i) {
+    if (int rc = check_probs(keys + i)) return rc;
+    tab.k[i] = keys[i];
+    gx = std::max(gx, ((keys[i].P + 31) / 32) * keys[i].frames);
+    gy = std::max(gy, keys[i].heads);
+  }
+  hipLaunchKernelGGL(ca_probs_multi_kernel, dim3(gx, gy, nkeys), dim3(64), 0, (hipStream_t)stream, tab);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t nkeys, void* stream) {
+  LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_select_multi: 1..%d keys", LVD_CA_MAX_KEYS);
+  KeyTable<lvd_ca_select_params> tab;
+  int blocks = 0;
+  size_t smem = 0;
+  bool com = false;
+  for (int i = 0; i < nkeys; ++i) {
+    if (int rc = check_select(keys + i)) return rc;
+    tab.k[i] = keys[i];
+    blocks = std::max(blocks, keys[i].frames * keys[i].heads * keys[i].ntok);
+    smem = std::max(smem, (size_t)keys[i].P * 5 + 16);
+    com = com || keys[i].com_loss_scale > 0.f;
+    LVD_CHECK((keys[i].com_loss_scale > 0.f) == (keys[0].com_loss_scale > 0.f), "ca_select_multi: the centre-of-mass term is on for all keys or for none");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (com) {
+    hipLaunchKernelGGL(ca_com_multi_kernel, dim3(blocks, nkeys), dim3(256), 0, s, tab);
+    LVD_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(ca_select_multi_kernel, dim3(blocks, nkeys), dim3(256), smem, s, tab);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_dq_multi(const lvd_ca_dq_params* keys, int32_t nkeys, void* stream) {
+  LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_dq_multi: 1..%d keys", LVD_CA_MAX_KEYS);
+  KeyTable<lvd_ca_dq_params> tab;
+  int gx = 0, gy = 0, nt = 0;
+  for (int i = 0; i < nkeys; ++i) {
+    if (int rc = check_dq(keys + i)) return rc;
+    tab.k[i] = keys[i];
+    gx = std::max(gx, ((keys[i].P + 31) / 32) * keys[i].frames);
+    gy = std::max(gy, keys[i].heads);
+    nt = std::max(nt, keys[i].ntok);
+  }
+  const dim3 grid(gx, gy, nkeys);
+  hipStream_t s = (hipStream_t)stream;
+  if (nt <= 2) hipLaunchKernelGGL(ca_dq_multi_kernel<2>, grid, dim3(64), 0, s, tab);
+  else if (nt <= 4) hipLaunchKernelGGL(ca_dq_multi_kernel<4>, grid, dim3(64), 0, s, tab);
+  else if (nt <= 8) hipLaunchKernelGGL(ca_dq_multi_kernel<8>, grid, dim3(64), 0, s, tab);
+  else hipLaunchKernelGGL(ca_dq_multi_kernel<MAXTOK>, grid, dim3(64), 0, s, tab);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) {
+  if (int rc = check_probs(p)) return rc;
   dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
   hipLaunchKernelGGL(ca_probs_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
   LVD_LAUNCH_CHECK();
@@ -475,8 +592,7 @@ extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) {
 }
 
 extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) {
-  LVD_CHECK(p && p->probs && p->dprobs && p->tok_obj && p->boxes && p->tok_weight && p->loss_partial && p->com_ws, "ca_select: null pointer");
-  LVD_CHECK(p->P == p->H * p->W && p->P <= 4096, "ca_select: P=%d must equal H*W and be <= 4096", p->P);
+  if (int rc = check_select(p)) return rc;
   hipStream_t s = (hipStream_t)stream;
   int blocks = p->frames * p->heads * p->ntok;
   if (p->com_loss_scale > 0.f) {
@@ -490,9 +606,7 @@ extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) {
 }
 
 extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) {
-  LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->dprobs && p->lse && p->dq, "ca_dq: null pointer");
-  LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_dq: ntok=%d outside 1..%d", p->ntok, MAXTOK);
-  LVD_CHECK(p->acc_mode >= 0 && p->acc_mode <= 3 && (p->acc_mode == 0 || (p->acc32 && p->ldacc % 4 == 0)), "ca_dq: acc_mode %d needs an fp32 accumulator", p->acc_mode);
+  if (int rc = check_dq(p)) return rc;
   dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
   if (p->ntok <= 2) hipLaunchKernelGGL(ca_dq_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, *p);
   else if (p->ntok <= 4) hipLaunchKernelGGL(ca_dq_kernel<4>, grid, dim3(64), 0, (hipStream_t)stream, *p);

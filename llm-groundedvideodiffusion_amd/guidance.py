@@ -109,17 +109,31 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
                                        _acc=(acc32, mode))
             off += n
         return dq
+    a, b, c, keep = _ca_params(q, k, heads, frames, layout, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                               com_loss_scale=com_loss_scale, loss_partial=loss_partial, want_dq=want_dq, use_ratio_based_loss=use_ratio_based_loss,
+                               attn_sync_weight=attn_sync_weight, boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed,
+                               boxdiff_L=boxdiff_L, _acc=_acc)
+    st = torch.cuda.current_stream().cuda_stream
+    hip.check(hip.lib().lvdhip_ca_probs(C.byref(a), st), "ca_probs")
+    hip.check(hip.lib().lvdhip_ca_select(C.byref(b), st), "ca_select")
+    if not want_dq:
+        return None
+    hip.check(hip.lib().lvdhip_ca_dq(C.byref(c), st), "ca_dq")
+    return keep["dq"]
+
+
+def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_weight, com_loss_scale, loss_partial, want_dq,
+               use_ratio_based_loss, attn_sync_weight, boxdiff_loss_scale, boxdiff_normed, boxdiff_L, _acc=None):
+    """The three parameter blocks of one key (probabilities, selection / loss, dQ) and the buffers they point into (`keep`)."""
     dev = q.device
     P = layout.H * layout.W
     assert q.shape[0] == frames * P, (q.shape, frames, P)
-    st = torch.cuda.current_stream().cuda_stream
     probs = torch.empty((frames, heads, layout.ntok, P), dtype=torch.float32, device=dev)
     lse = torch.empty((frames, heads, P), dtype=torch.float32, device=dev)
     a = hip.CaProbsParams()
     a.q, a.ldq, a.k, a.ldk = q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0)
     a.frames, a.heads, a.P, a.ntext, a.scale = frames, heads, P, ntext, 0.125
     a.tok_ids, a.ntok, a.probs, a.lse = layout.tok_ids.data_ptr(), layout.ntok, probs.data_ptr(), lse.data_ptr()
-    hip.check(hip.lib().lvdhip_ca_probs(C.byref(a), st), "ca_probs")
 
     dprobs = torch.empty_like(probs)
     com_ws = torch.empty((frames, heads, layout.ntok, 4), dtype=torch.float32, device=dev)
@@ -133,24 +147,50 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
     b.boxdiff_loss_scale, b.boxdiff_normed, b.boxdiff_L = float(boxdiff_loss_scale), int(bool(boxdiff_normed)), int(boxdiff_L)
     if use_ratio_based_loss:
         warnings.warn("Using ratio-based loss, which is deprecated. Max-based loss is recommended. The scale may be different.")
-    hip.check(hip.lib().lvdhip_ca_select(C.byref(b), st), "ca_select")
-    if not want_dq:
-        return None
-    acc32, mode = _acc if _acc is not None else (None, 0)
-    dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev) if mode in (0, 3) else None
-    c = hip.CaDqParams()
-    c.q, c.ldq, c.k, c.ldk = a.q, a.ldq, a.k, a.ldk
-    c.frames, c.heads, c.P, c.ntext, c.scale = frames, heads, P, ntext, 0.125
-    c.tok_ids, c.ntok = a.tok_ids, a.ntok
-    c.probs, c.dprobs, c.lse = probs.data_ptr(), dprobs.data_ptr(), lse.data_ptr()
-    if dq is not None:
-        c.dq, c.lddq = dq.data_ptr(), dq.stride(0)
-    else:  # accumulate-only chunk: the bf16 output is not written (any valid pointer)
-        c.dq, c.lddq = acc32.data_ptr(), 0
-    if acc32 is not None:
-        c.acc32, c.ldacc, c.acc_mode = acc32.data_ptr(), acc32.stride(0), mode
-    hip.check(hip.lib().lvdhip_ca_dq(C.byref(c), st), "ca_dq")
-    return dq
+    keep = dict(probs=probs, lse=lse, dprobs=dprobs, com_ws=com_ws, dq=None)
+    c = None
+    if want_dq:
+        acc32, mode = _acc if _acc is not None else (None, 0)
+        dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev) if mode in (0, 3) else None
+        c = hip.CaDqParams()
+        c.q, c.ldq, c.k, c.ldk = a.q, a.ldq, a.k, a.ldk
+        c.frames, c.heads, c.P, c.ntext, c.scale = frames, heads, P, ntext, 0.125
+        c.tok_ids, c.ntok = a.tok_ids, a.ntok
+        c.probs, c.dprobs, c.lse = probs.data_ptr(), dprobs.data_ptr(), lse.data_ptr()
+        if dq is not None:
+            c.dq, c.lddq = dq.data_ptr(), dq.stride(0)
+        else:  # accumulate-only chunk: the bf16 output is not written (any valid pointer)
+            c.dq, c.lddq = acc32.data_ptr(), 0
+        if acc32 is not None:
+            c.acc32, c.ldacc, c.acc_mode = acc32.data_ptr(), acc32.stride(0), mode
+        keep["dq"] = dq
+    return a, b, c, keep
+
+
+def ca_energy_loss_and_dq_all_keys(items, frames, *, ntext, grad_scale, fg_weight, bg_weight, com_loss_scale, **loss_options):
+    """Every key of a guidance iteration in ONE launch per stage (probabilities / selection + loss / dQ: 3 launches instead of 3 per key;
+    csrc/guidance_loss.hip *_multi).  `items`: (q, k, heads, layout, loss_partial slice) per key.  Same bits as the key-by-key calls.
+    Layouts with more object tokens than a launch holds (chunked dQ accumulation) take the key-by-key path."""
+    if len(items) > hip.CA_MAX_KEYS or any(lay.ntok > MAX_TOKENS_PER_LAUNCH for _, _, _, lay, _ in items):
+        return [ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                      com_loss_scale=com_loss_scale, loss_partial=part, **loss_options) for q, k, heads, lay, part in items]
+    opts = dict(use_ratio_based_loss=False, attn_sync_weight=0.0, boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1)
+    opts.update(loss_options)
+    n = len(items)
+    A, B, Cq = (hip.CaProbsParams * n)(), (hip.CaSelectParams * n)(), (hip.CaDqParams * n)()
+    keeps = []
+    for i, (q, k, heads, lay, part) in enumerate(items):
+        if lay.ntok and int(lay.tok_ids_host.max()) >= ntext:  # the reference indexes attn[..., pos] and raises the same way
+            raise IndexError(f"object token position {int(lay.tok_ids_host.max())} is out of bounds for {ntext} text tokens")
+        a, b, c, keep = _ca_params(q, k, heads, frames, lay, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                   com_loss_scale=com_loss_scale, loss_partial=part, want_dq=True, **opts)
+        A[i], B[i], Cq[i] = a, b, c
+        keeps.append(keep)
+    st = torch.cuda.current_stream().cuda_stream
+    hip.check(hip.lib().lvdhip_ca_probs_multi(A, n, st), "ca_probs_multi")
+    hip.check(hip.lib().lvdhip_ca_select_multi(B, n, st), "ca_select_multi")
+    hip.check(hip.lib().lvdhip_ca_dq_multi(Cq, n, st), "ca_dq_multi")
+    return [kp["dq"] for kp in keeps]
 
 
 def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_positions, guidance_attn_keys, *, loss_scale,
@@ -177,15 +217,18 @@ def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_p
         sizes.append(frames * heads * sum(len(p) for p in object_positions))
     partial = torch.empty((sum(sizes),), dtype=torch.float32, device=latents.device)
     off = 0
+    items = []
     for key, n in zip(keys, sizes):
         q, k, heads, g = collect["q"][key]
         lay = layouts.get((g.H, g.W))
         if lay is None:
             lay = layouts[(g.H, g.W)] = GuidanceLayout(bboxes, object_positions, frames, g.H, g.W, fg_top_p, bg_top_p, latents.device)
-        dq = ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=text.ntext, grad_scale=grad_scale, fg_weight=fg_weight,
-                                   bg_weight=bg_weight, com_loss_scale=com_loss_scale, loss_partial=partial[off:off + n], **loss_options)
-        tape.accumulate(q, dq)
+        items.append((q, k, heads, lay, partial[off:off + n]))
         off += n
+    dqs = ca_energy_loss_and_dq_all_keys(items, frames, ntext=text.ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                         com_loss_scale=com_loss_scale, **loss_options)
+    for (q, _, _, _, _), dq in zip(items, dqs):
+        tape.accumulate(q, dq)
     if saved_attn is not None:  # visualisation only (return_saved_attn): the full maps, as AttnProcessor.__call__ would have saved them
         for key in keys:
             q, k, heads, g = collect["q"][key]

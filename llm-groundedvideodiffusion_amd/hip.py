@@ -157,6 +157,9 @@ SYMBOLS = {
     "lvdhip_ca_probs": [_P(CaProbsParams), C.c_void_p],
     "lvdhip_ca_select": [_P(CaSelectParams), C.c_void_p],
     "lvdhip_ca_dq": [_P(CaDqParams), C.c_void_p],
+    "lvdhip_ca_probs_multi": [_P(CaProbsParams), i32, C.c_void_p],
+    "lvdhip_ca_select_multi": [_P(CaSelectParams), i32, C.c_void_p],
+    "lvdhip_ca_dq_multi": [_P(CaDqParams), i32, C.c_void_p],
     "lvdhip_latents_to_tokens": [C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, f32, C.c_void_p],
     "lvdhip_tokens_to_latents": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, C.c_void_p],
     "lvdhip_tokens_grad_to_latents": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, f32, C.c_void_p],
@@ -183,6 +186,7 @@ _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
 ABI_VERSION = 102
+CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 
 def lib():

@@ -132,6 +132,35 @@ def test_fused_loss_optional_terms_vs_oracle_and_reference(case):
     assert rel(dq, gq) < 1.5e-2, (case, rel(dq, gq))
 
 
+@pytest.mark.parametrize("com", [0.0, 0.03])
+def test_fused_loss_all_keys_in_one_launch_set_equals_key_by_key(com):
+    """ca_*_multi (blockIdx.z = key): six keys of different resolutions / head counts in three launches give the bits of 18 single-key
+    launches — loss partials and dQ."""
+    frames, nt = 6, 77
+    keysz = [(8, 12, 3), (4, 6, 5), (4, 6, 5), (8, 12, 3), (16, 24, 2), (4, 6, 5)]  # (H, W, heads)
+    bboxes = [[[0.1, 0.2, 0.55 + 0.02 * f, 0.8] for f in range(frames)], [[0.5, 0.5, 0.9, 0.95] if f != 2 else [0.0] * 4 for f in range(frames)]]
+    pos = [[2, 3], [6]]
+    lays, items_a, items_b = {}, [], []
+    ntok = 3
+    tot = sum(frames * h * ntok for _, _, h in keysz)
+    pa, pb = torch.zeros(tot, device=DEV), torch.zeros(tot, device=DEV)
+    off = 0
+    for i, (Hh, Ww, heads) in enumerate(keysz):
+        q = rnd(frames * Hh * Ww, heads * 64, seed=10 + i, scale=1.5).bfloat16()
+        k = rnd(nt, heads * 64, seed=30 + i).bfloat16()
+        lay = lays.get((Hh, Ww)) or lays.setdefault((Hh, Ww), guidance.GuidanceLayout(bboxes, pos, frames, Hh, Ww, 0.3, 0.4, DEV))
+        n = frames * heads * ntok
+        items_a.append((q, k, heads, lay, pa[off:off + n]))
+        items_b.append((q, k, heads, lay, pb[off:off + n]))
+        off += n
+    kw = dict(ntext=nt, grad_scale=0.4, fg_weight=1.0, bg_weight=2.0, com_loss_scale=com)
+    dq_multi = guidance.ca_energy_loss_and_dq_all_keys(items_a, frames, **kw)
+    dq_single = [guidance.ca_energy_loss_and_dq(q, k, heads, frames, lay, loss_partial=part, **kw) for q, k, heads, lay, part in items_b]
+    assert torch.equal(pa, pb) and float(pa.abs().sum()) > 0
+    for a, b in zip(dq_multi, dq_single):
+        assert torch.equal(a, b) and float(a.float().abs().sum()) > 0
+
+
 def test_fused_loss_many_object_tokens_and_bounds():
     """More object tokens than one launch keeps per query (csrc/guidance_loss.hip MAXTOK = 16) run in token chunks — loss and dQ
     are per-token / linear in the tokens; a token position beyond the text length raises IndexError like the reference's indexing."""

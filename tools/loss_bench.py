@@ -22,26 +22,39 @@ lay = {}
 partial = torch.empty(sum(F * heads * ntok for _, _, heads in layers), device=dev)
 
 
-def iteration():
-    off = 0
+def items():
+    off, out = 0, []
     for (h, w, heads), q, k in zip(layers, qs, ks):
         L = lay.get((h, w)) or lay.setdefault((h, w), guidance.GuidanceLayout(bboxes, positions, F, h, w, 0.25, 0.25, dev))
         n = F * heads * ntok
-        guidance.ca_energy_loss_and_dq(q, k, heads, F, L, ntext=77, grad_scale=1.0, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.0,
-                                       loss_partial=partial[off:off + n])
+        out.append((q, k, heads, L, partial[off:off + n]))
         off += n
+    return out
 
 
-for _ in range(3):
-    iteration()
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(20):
-    iteration()
-e.record()
-e.synchronize()
-us = s.elapsed_time(e) / 20 * 1e3
+KW = dict(ntext=77, grad_scale=1.0, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.0)
+
+
+def key_by_key():
+    for q, k, heads, L, part in items():
+        guidance.ca_energy_loss_and_dq(q, k, heads, F, L, loss_partial=part, **KW)
+
+
+def all_keys():
+    guidance.ca_energy_loss_and_dq_all_keys(items(), F, **KW)
+
+
 mb = sum(2 * q.numel() * 2 for q in qs) / 1e6
-print(f"guidance loss, 6 keys, {ntok} object tokens: {us:.0f} us per iteration ({us / 6:.0f} us per key, 3 launches each); "
-      f"algorithmic traffic {mb:.0f} MB (read Q + write dQ) -> {mb / us:.3f} TB/s = {mb / us / 8.0:.3f} of the 8 TB/s HBM figure")
+for name, fn, launches in (("key by key", key_by_key, 18), ("all keys per launch", all_keys, 3)):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        fn()
+    e.record()
+    e.synchronize()
+    us = s.elapsed_time(e) / 20 * 1e3
+    print(f"guidance loss, 6 keys, {ntok} object tokens, {name} ({launches} launches): {us:.0f} us per iteration; "
+          f"algorithmic traffic {mb:.0f} MB (read Q + write dQ) -> {mb / us:.3f} TB/s = {mb / us / 8.0:.3f} of the 8 TB/s HBM figure")
