@@ -294,8 +294,7 @@ def main():
         """CFG forward + fused update of all V samples in one batch-2V pass."""
         t = int(sched.timesteps[i])
         lats = [latents] + [l for l, _ in more]
-        x = torch.cat([l.expand(2, -1, -1, -1, -1) for l in lats]).contiguous()
-        eps = engine.forward(x, t, text=text_cfg_all)
+        eps = engine.forward_cfg(torch.cat(lats).contiguous(), t, text=text_cfg_all)
         a_t, s_t, c_x, c_0, c_1 = sched.coefficients(i)
         for v, (l, xp) in enumerate(zip(lats, [sampler.x0_prev] + x0_prev_more)):
             ops.cfg_dpm_step(eps[2 * v:2 * v + 1], eps[2 * v + 1:2 * v + 2], sampler.guidance_scale, l, xp, a_t, s_t, c_x, c_0, c_1)
@@ -406,9 +405,10 @@ def main():
         dom = max(agg, key=lambda m: agg[m][1])
         n, secs, fl = agg[dom]
         ach = fl / secs / 1e12
-        traffic, tnote = None, "no profiles/r03_gemm_traffic.json next to bench.py"
-        tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
-        tsource = "profiles/r03_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes: tools/traffic_passes.sh; NOT measured in this run)"
+        tfile = next((f for f in ("r04_gemm_traffic.json", "r03_gemm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_gemm_traffic.json")
+        traffic, tnote = None, f"no profiles/{tfile} next to bench.py"
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        tsource = f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes: tools/traffic_passes.sh; NOT measured in this run)"
         if os.path.exists(tpath):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py, rolled up by tools/pmc_traffic.py
             tj = json.load(open(tpath)).get(keyname[dom])
             if tj:
@@ -482,6 +482,11 @@ def main():
             "unguided_mfma_frac": round(tf_cfg / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "loss_finite": finite,
             "guided_step_is": "guidance.hip_latent_backward_guidance (one iteration; the returned loss tensor is carried into the next step, whose entry check waits for its pinned host copy) + CFG forward + fused CFG/DPM update",
+            "cfg_shared_prefix": bool(engine.cfg_shared_prefix),
+            "cfg_shared_prefix_note": "the (uncond, cond) items of the CFG batch are the SAME latents (reference: torch.cat([latents] * 2)) and stay identical "
+                                      "until the first text-dependent layer; that prefix (conv_in, transformer_in, first resnet / temporal conv / spatial self-"
+                                      "attention) runs once per sample and is duplicated there.  step_algorithmic_tflop still counts it twice, as the reference "
+                                      "module does; LVD_CFG_SHARED_PREFIX=0 disables it",
             "gemm_autotune_table": table_loaded, "rccl_ranks_seen": rccl_seen,
             "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,

@@ -120,6 +120,9 @@ class HipUNet3D:
         # separate LayerNorm launches (A/B knob)
         import os
         self.ln_fold = os.environ.get("LVD_LN_FOLD", "1") != "0"
+        # classifier-free guidance: the part of the network in front of the first text-dependent layer once per sample (forward(cfg_pairs=True));
+        # LVD_CFG_SHARED_PREFIX=0 makes the callers feed the duplicated batch like the reference does (A/B knob)
+        self.cfg_shared_prefix = os.environ.get("LVD_CFG_SHARED_PREFIX", "1") != "0"
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -444,8 +447,17 @@ class HipUNet3D:
             tape.push(bw)
         return self._linear(h, name + ".net.2", tape=tape, res=res, alpha=alpha)
 
+    @staticmethod
+    def _pair_rows(x, g: Geom):
+        """[sample_0, sample_1, ...] -> [sample_0, sample_0, sample_1, sample_1, ...] (rows of a sample stay together): the point where the
+        (uncond, cond) halves of a classifier-free-guidance pair, identical so far, start to differ.  One device copy."""
+        rps = g.F * g.HW
+        out = torch.empty((2 * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+        out.view(g.B, 2, rps, x.shape[1]).copy_(x.view(g.B, 1, rps, x.shape[1]).expand(-1, 2, -1, -1))
+        return out
+
     # ------------------------------------------------------------------ composite blocks
-    def _transformer_block(self, hs, name, heads, *, tape, spatial, g: Geom, text=None, objs=None, key=None, collect=None):
+    def _transformer_block(self, hs, name, heads, *, tape, spatial, g: Geom, text=None, objs=None, key=None, collect=None, pair_split=False):
         if spatial:
             samples, seq, rmap = g.B * g.F, g.HW, ops.RowMap(1, g.HW, 0, 1)
         else:
@@ -453,6 +465,11 @@ class HipUNet3D:
         n1 = self._layernorm(hs, name + ".norm1", tape=tape, fold=True)
         o = self._self_attention(n1, name + ".attn1", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
         hs = self._linear(o, name + ".attn1.to_out.0", tape=tape, res=hs)
+        if pair_split:  # first text- (or grounding-) dependent layer of the network: from here on each sample is an (uncond, cond) pair
+            assert spatial and tape is None
+            hs = self._pair_rows(hs, g)
+            g = Geom(2 * g.B, g.F, g.H, g.W)
+            samples = g.B * g.F
         if objs is not None and (name + ".fuser.linear.weight") in self.w:
             hs = self._fuser(hs, name + ".fuser", heads, objs, g)
         n2 = self._layernorm(hs, name + ".norm2", tape=tape, fold=True)
@@ -476,11 +493,12 @@ class HipUNet3D:
         n2 = self._layernorm(hs, name + ".norm2", tape=None)
         return self._feed_forward(n2, name + ".ff", hs, tape=None, alpha=self.alpha[name + ".alpha_dense"])
 
-    def _transformer2d(self, x, name, heads, g: Geom, text, *, tape, objs=None, key=None, collect=None):
+    def _transformer2d(self, x, name, heads, g: Geom, text, *, tape, objs=None, key=None, collect=None, pair_split=False):
         h = self._groupnorm(x, name + ".norm", g.HW, tape=tape, eps=1e-6, silu=False)
         hs = self._linear(h, name + ".proj_in", tape=tape)
-        hs = self._transformer_block(hs, name + ".transformer_blocks.0", heads, tape=tape, spatial=True, g=g, text=text, objs=objs, key=key, collect=collect)
-        return self._linear(hs, name + ".proj_out", tape=tape, res=x)
+        hs = self._transformer_block(hs, name + ".transformer_blocks.0", heads, tape=tape, spatial=True, g=g, text=text, objs=objs, key=key, collect=collect,
+                                     pair_split=pair_split)
+        return self._linear(hs, name + ".proj_out", tape=tape, res=self._pair_rows(x, g) if pair_split else x)
 
     def _transformer_temporal(self, x, name, heads, g: Geom, *, tape):
         h = self._groupnorm(x, name + ".norm", g.F * g.HW, tape=tape, eps=1e-6, silu=False)
@@ -527,8 +545,16 @@ class HipUNet3D:
 
     # ------------------------------------------------------------------ whole model
     def forward(self, sample, timestep, encoder_hidden_states=None, *, text: TextCache = None, gligen=None, fuser_enabled=True,
-                tape: Tape = None, collect=None):
+                tape: Tape = None, collect=None, cfg_pairs=False):
         """sample (B,4,F,h,w) fp32 CUDA -> noise prediction (B,4,F,h,w) fp32.
+
+        cfg_pairs=True: classifier-free guidance on V samples.  `sample` holds the V latents ONCE; `text` (and `gligen`) hold 2V items
+        ordered [uncond_0, cond_0, uncond_1, cond_1, ...]; the result has 2V items in that order.  The reference feeds the UNet
+        torch.cat([latents] * 2) (controllable_pipeline…py:908-912), i.e. two IDENTICAL inputs that only start to differ at the first
+        layer that reads the text (attn2 of the first spatial transformer) or the grounding tokens (its fuser): everything before that
+        — conv_in, transformer_in, the first ResnetBlock2D / TemporalConvLayer, the first spatial self-attention — is computed once per
+        sample and its rows are duplicated there (`_pair_rows`), as is the first skip connection when the up path reads it.  Same
+        function, half the work on that prefix (level 0: one of the most expensive stretches of the network).
 
         collect = {"keys": [...], "q": {}, "stop_after": key}: store (q, k_text, heads, geom) of the listed
         cross-attention layers (attn_key tuples as in the reference) and optionally stop there.
@@ -544,6 +570,10 @@ class HipUNet3D:
         g = Geom(B, Fr, H, W)
         if text is None:
             text = self.encode_text(encoder_hidden_states)
+        pending = bool(cfg_pairs)  # the (uncond, cond) halves have not diverged yet
+        if pending:
+            assert tape is None and collect is None, "cfg_pairs is a plain (unrecorded) forward"
+            B = 2 * B  # batch of the result and of everything behind the split
         assert text.B == B
         if torch.is_tensor(timestep):
             t = timestep.to(self.dev, torch.float32).reshape(-1).expand(B).contiguous()
@@ -562,19 +592,25 @@ class HipUNet3D:
             objs = self.position_net(gligen["boxes"], gligen["masks"], gligen["positive_embeddings"])
 
         def layer(prefix, j, key, x, g, has_attn, c, skip=None):
+            nonlocal pending
             x = self._resnet(x, f"{prefix}.resnets.{j}", g, temb_rows, tape=tape, skip=skip)
             x = self._temporal_conv(x, f"{prefix}.temp_convs.{j}", g, tape=tape)
             if has_attn:
-                x = self._transformer2d(x, f"{prefix}.attentions.{j}", c // dh, g, text, tape=tape, objs=objs, key=key, collect=collect)
+                x = self._transformer2d(x, f"{prefix}.attentions.{j}", c // dh, g, text, tape=tape, objs=objs, key=key, collect=collect, pair_split=pending)
+                if pending:
+                    pending, g = False, Geom(2 * g.B, g.F, g.H, g.W)
                 x = self._transformer_temporal(x, f"{prefix}.temp_attentions.{j}", c // dh, g, tape=tape)
-            return x
+            return x, g
+
+        def paired(x, gx):  # a tensor produced before the split, used behind it
+            return (self._pair_rows(x, gx), Geom(2 * gx.B, gx.F, gx.H, gx.W)) if cfg_pairs and not pending and gx.B * 2 == B else (x, gx)
 
         try:
             skips = [(x, g)]
             for i, btype in enumerate(cfg.down_block_types):
                 c = boc[i]
                 for j in range(cfg.layers_per_block):
-                    x = layer(f"down_blocks.{i}", j, ("down", i, j, 0), x, g, btype == "CrossAttnDownBlock3D", c)
+                    x, g = layer(f"down_blocks.{i}", j, ("down", i, j, 0), x, g, btype == "CrossAttnDownBlock3D", c)
                     skips.append((x, g))
                 if i != len(boc) - 1:
                     x, g = self._conv3x3(x, f"down_blocks.{i}.downsamplers.0.conv", g, tape=tape, stride=2)
@@ -582,7 +618,9 @@ class HipUNet3D:
             c = boc[-1]
             x = self._resnet(x, "mid_block.resnets.0", g, temb_rows, tape=tape)
             x = self._temporal_conv(x, "mid_block.temp_convs.0", g, tape=tape)
-            x = self._transformer2d(x, "mid_block.attentions.0", c // dh, g, text, tape=tape, objs=objs, key=("mid", 0, 0, 0), collect=collect)
+            x = self._transformer2d(x, "mid_block.attentions.0", c // dh, g, text, tape=tape, objs=objs, key=("mid", 0, 0, 0), collect=collect, pair_split=pending)
+            if pending:  # a topology without attention in the down path
+                pending, g = False, Geom(2 * g.B, g.F, g.H, g.W)
             x = self._transformer_temporal(x, "mid_block.temp_attentions.0", c // dh, g, tape=tape)
             x = self._resnet(x, "mid_block.resnets.1", g, temb_rows, tape=tape)
             x = self._temporal_conv(x, "mid_block.temp_convs.1", g, tape=tape)
@@ -590,9 +628,9 @@ class HipUNet3D:
             for i, btype in enumerate(cfg.up_block_types):
                 c = rev[i]
                 for j in range(cfg.layers_per_block + 1):
-                    skip, gs = skips.pop()
-                    assert (gs.H, gs.W) == (g.H, g.W)
-                    x = layer(f"up_blocks.{i}", j, ("up", i, j, 0), x, g, btype == "CrossAttnUpBlock3D", c, skip=skip)
+                    skip, gs = paired(*skips.pop())
+                    assert (gs.H, gs.W, gs.B) == (g.H, g.W, g.B)
+                    x, g = layer(f"up_blocks.{i}", j, ("up", i, j, 0), x, g, btype == "CrossAttnUpBlock3D", c, skip=skip)
                 if i != len(boc) - 1:
                     gt = skips[-1][1]
                     x, g = self._conv3x3(x, f"up_blocks.{i}.upsamplers.0.conv", g, tape=tape, upsample=1, up_to=(gt.H, gt.W))
@@ -603,6 +641,14 @@ class HipUNet3D:
         h = self._groupnorm(x, "conv_norm_out", g.HW, tape=tape, eps=cfg.norm_eps, silu=True)
         out32, _ = self._conv3x3(h, "conv_out", g, tape=None, out_fp32=True)
         return ops.tokens_to_latents(out32, B, cfg.out_channels, Fr, H, W)
+
+    def forward_cfg(self, latents, timestep, *, text: TextCache, gligen=None, fuser_enabled=True):
+        """Noise predictions of V samples for classifier-free guidance: latents (V,4,F,h,w), text / gligen of 2V items ordered
+        [uncond_0, cond_0, ...] -> (2V,4,F,h,w) in that order (controllable_pipeline…py:908-923).  The shared prefix runs once per sample."""
+        if self.cfg_shared_prefix:
+            return self.forward(latents, timestep, text=text, gligen=gligen, fuser_enabled=fuser_enabled, cfg_pairs=True)
+        x2 = latents.repeat_interleave(2, 0).contiguous()
+        return self.forward(x2, timestep, text=text, gligen=gligen, fuser_enabled=fuser_enabled)
 
     def input_gradient(self, tape: Tape, g: Geom, scale=1.0):
         """After tape.backward(): gradient w.r.t. the (B,4,F,h,w) latents."""

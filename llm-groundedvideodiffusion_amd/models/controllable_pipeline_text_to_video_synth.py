@@ -217,8 +217,8 @@ class TextToVideoSDPipeline:
                     if st["guidance_callback"] is not None and i % callback_steps == 0:
                         st["guidance_callback"](i, t, st["latents"], None, ret[2] if return_guidance_saved_attn else None)
             fuser_on = all(m.enabled for m in self.unet.modules() if type(m).__name__ == "GatedSelfAttentionDense")
-            x2 = torch.cat([st["latents"].expand(2, -1, -1, -1, -1) for st in states]).contiguous()
-            eps = engine.forward(x2, t, text=text_cfg, gligen=gligen, fuser_enabled=fuser_on)
+            xs = torch.cat([st["latents"] for st in states]).contiguous()
+            eps = engine.forward_cfg(xs, t, text=text_cfg, gligen=gligen, fuser_enabled=fuser_on)  # [uncond_0, cond_0, uncond_1, ...]
             a_t, s_t, c_x, c_0, c_1 = self.scheduler.coefficients(i)
             for v, st in enumerate(states):
                 st["latents"] = st["latents"].contiguous()

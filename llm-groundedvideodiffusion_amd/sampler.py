@@ -102,8 +102,7 @@ class HipSampler:
         """latents (1,4,F,h,w) fp32 is updated in place; text_cfg = TextCache of [negative; positive] prompts."""
         sch = self.schedule
         t = int(sch.timesteps[i])
-        x2 = latents.expand(2, -1, -1, -1, -1).contiguous()
-        eps = self.engine.forward(x2, t, text=text_cfg, gligen=gligen, fuser_enabled=fuser_enabled)
+        eps = self.engine.forward_cfg(latents, t, text=text_cfg, gligen=gligen, fuser_enabled=fuser_enabled)  # [uncond, cond]
         a_t, s_t, c_x, c_0, c_1 = sch.coefficients(i)
         ops.cfg_dpm_step(eps[0:1], eps[1:2], self.guidance_scale, latents, self.x0_prev, a_t, s_t, c_x, c_0, c_1)
         sch.advance()

@@ -97,3 +97,41 @@ def test_resized_upsample_conv_backward_vs_autograd():
     tape.accumulate(out, dy.cuda())
     tape.backward()
     assert rel(tape.pop(xg), xr.grad.permute(0, 2, 3, 1).reshape(-1, C)) < 1e-2
+
+
+def test_cfg_shared_prefix_equals_the_duplicated_batch():
+    """forward(cfg_pairs=True) — the layers in front of the first text-dependent one once per sample, rows duplicated there — against the
+    reference's form, a forward of torch.cat([latents] * 2): the same function (the two batch items are identical until attn2 of the first
+    spatial transformer reads the text), so the only difference is the bf16 rounding of tile geometries picked for half the rows.  Plain and
+    gated (GLIGEN fusers on: the split sits in front of the fuser) topologies, one and two samples."""
+    from lvd_amd.weights import TINY
+    for gated in (False, True):
+        cfg = UNetConfig(attention_type="gated" if gated else "default", **TINY)
+        net = HipUNet3D(cfg, synthetic_state_dict(cfg, seed=0))
+        gen = torch.Generator().manual_seed(3)
+        for V in (1, 2):
+            Fr = 4
+            lat = torch.randn(V, 4, Fr, 16, 16, generator=gen).cuda()
+            ehs = torch.randn(2 * V, 77, cfg.cross_attention_dim, generator=gen).cuda()
+            text = net.encode_text(ehs)
+            gl = None
+            if gated:
+                gl = {"boxes": torch.rand(2 * V * Fr, 30, 4, generator=gen), "masks": (torch.rand(2 * V * Fr, 30, generator=gen) > 0.5).float(),
+                      "positive_embeddings": torch.randn(2 * V * Fr, 30, cfg.cross_attention_dim, generator=gen)}
+            full = net.forward(lat.repeat_interleave(2, 0).contiguous(), 500, text=text, gligen=gl)
+            shared = net.forward(lat, 500, text=text, gligen=gl, cfg_pairs=True)
+            assert shared.shape == full.shape == (2 * V, 4, Fr, 16, 16)
+            err = ((shared - full).norm() / full.norm()).item()
+            print(f"gated={gated} V={V}: shared-prefix vs duplicated batch rel-L2 {err:.2e}")
+            assert err < 4e-2, err  # the batch-consistency bound of test_gated_full_size_properties: bf16 rounding of other tile geometries
+            assert ((shared[0] - shared[1]).norm() / shared.norm()).item() > 1e-3  # the halves really differ (other text)
+            net.cfg_shared_prefix = False
+            assert torch.equal(net.forward_cfg(lat, 500, text=text, gligen=gl), full)  # the knob: exactly the duplicated batch
+            net.cfg_shared_prefix = True
+        # pairing order: two copies of ONE sample with the same (uncond, cond) texts must give the same pair twice
+        lat1 = torch.randn(1, 4, 4, 16, 16, generator=gen).cuda()
+        ehs1 = torch.randn(2, 77, cfg.cross_attention_dim, generator=gen).cuda()
+        twice = net.forward(torch.cat([lat1, lat1]), 500, text=net.encode_text(torch.cat([ehs1, ehs1])), cfg_pairs=True)
+        assert ((twice[0:2] - twice[2:4]).norm() / twice[0:2].norm()).item() < 1e-3
+        once = net.forward(lat1, 500, text=net.encode_text(ehs1), cfg_pairs=True)
+        assert ((twice[0:2] - once).norm() / once.norm()).item() < 4e-2
