@@ -120,6 +120,7 @@ class HipUNet3D:
         # separate LayerNorm launches (A/B knob)
         import os
         self.ln_fold = os.environ.get("LVD_LN_FOLD", "1") != "0"
+        self.ln_fold_all = os.environ.get("LVD_LN_FOLD", "1") != "narrow"
         # classifier-free guidance: the part of the network in front of the first text-dependent layer once per sample (forward(cfg_pairs=True));
         # LVD_CFG_SHARED_PREFIX=0 makes the callers feed the duplicated batch like the reference does (A/B knob)
         self.cfg_shared_prefix = os.environ.get("LVD_CFG_SHARED_PREFIX", "1") != "0"
@@ -462,7 +463,13 @@ class HipUNet3D:
             samples, seq, rmap = g.B * g.F, g.HW, ops.RowMap(1, g.HW, 0, 1)
         else:
             samples, seq, rmap = g.B * g.HW, g.F, ops.RowMap(g.HW, g.F * g.HW, 1, g.HW)
-        n1 = self._layernorm(hs, name + ".norm1", tape=tape, fold=True)
+        # LayerNorm fold (statistics launch + row scaling in the consumer's epilogue).  The scaling costs the epilogue two FMAs and two LDS
+        # reads per output element, i.e. it grows with N, while the saved LayerNorm pass does not: at level 0, batch 2, isolated launches
+        # (tools/step_gemm_profile.py) to_q (N = C) +0 us for 14 us saved, to_qkv (N = 3C) +13 us, ff.net.0.proj (N = 8C, GEGLU) +36 us.  In the
+        # step itself folding every norm still measures best (same box: 116.4 ms all / 117.1 ms narrow consumers only / 117.4 ms none): the
+        # consumer no longer waits for a full LayerNorm pass to drain.  LVD_LN_FOLD=narrow folds norm2 -> to_q of the spatial blocks only.
+        fold_all = self.ln_fold_all
+        n1 = self._layernorm(hs, name + ".norm1", tape=tape, fold=fold_all)
         o = self._self_attention(n1, name + ".attn1", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
         hs = self._linear(o, name + ".attn1.to_out.0", tape=tape, res=hs)
         if pair_split:  # first text- (or grounding-) dependent layer of the network: from here on each sample is an (uncond, cond) pair
@@ -472,13 +479,13 @@ class HipUNet3D:
             samples = g.B * g.F
         if objs is not None and (name + ".fuser.linear.weight") in self.w:
             hs = self._fuser(hs, name + ".fuser", heads, objs, g)
-        n2 = self._layernorm(hs, name + ".norm2", tape=tape, fold=True)
+        n2 = self._layernorm(hs, name + ".norm2", tape=tape, fold=spatial or fold_all)
         if spatial:
             o = self._cross_attention(n2, name + ".attn2", heads, text, g, tape=tape, key=key, collect=collect)
         else:
             o = self._self_attention(n2, name + ".attn2", heads, samples=samples, seq=seq, rowmap=rmap, tape=tape)
         hs = self._linear(o, name + ".attn2.to_out.0", tape=tape, res=hs)
-        n3 = self._layernorm(hs, name + ".norm3", tape=tape, fold=True)
+        n3 = self._layernorm(hs, name + ".norm3", tape=tape, fold=fold_all)
         return self._feed_forward(n3, name + ".ff", hs, tape=tape)
 
     def _fuser(self, hs, name, heads, objs, g: Geom):
