@@ -76,6 +76,7 @@ enum {
   LVD_GEMM_V_ADMA = 100,
   /* + LVD_GEMM_V_ADMA64 on RING256W / SPLITK_WIDE / RING256W_TAIL: 64-deep K tiles in a two-slot ring — every DMA instruction
      moves 8 rows x one full 128-byte line (plain loader, K % 64 == 0, K >= 128; anything else runs the + LVD_GEMM_V_ADMA form).
+     Since round 4 also on RING128 / RING256N / RING128x320 / SPLITK (205 / 209 / 217 / 220): the same 4-wave loops with 64-deep tiles.
      A code that names no geometry (e.g. 141, 210) is an error, not a fallback. */
   LVD_GEMM_V_ADMA64 = 200
 };

@@ -365,13 +365,13 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
     v = v == LVD_GEMM_V_CONV_HALO ? LVD_GEMM_V_RING256W : LVD_GEMM_V_SPLITK_WIDE;
   }
   const int a100 = adma ? 100 : 0;  // geometries without a 64-deep form take the 32-deep asm-DMA one
-  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5 + (v <= 6 ? a100 : 0));
+  if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5 + (v <= 6 ? (v == 5 ? adma : a100) : 0));
   if (v == 14 && !adma) return lvd_gemm_ring_dispatch(p, stream, 8);
-  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20 + a100);
+  if (v == 20) return lvd_gemm_ring_dispatch(p, stream, 20 + adma);
   if (v == LVD_GEMM_V_SPLITK_WIDE) return lvd_gemm_ring_dispatch(p, stream, (n320 && wide320_fills_better(p) ? 24 : 25) + adma);
-  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 12 : 0) + a100);
+  if (v == 17) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 12 : 0) + adma);
   if (v == 11) return lvd_gemm_ring_dispatch(p, stream, (n320 ? 4 : 5) + adma);
-  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, ((p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3) + a100);
+  if (v == 9) return lvd_gemm_ring_dispatch(p, stream, ((p->act != LVD_ACT_GEGLU && p->N % 160 == 0) ? 2 : 3) + adma);
   if (adma) return 3;
   if (p->ln_mean_rstd) return 4;  // the register-staged kernels have no LayerNorm-folded epilogue
   if (v == 1) return launch_gemm<32, 3>(p, grid, s);

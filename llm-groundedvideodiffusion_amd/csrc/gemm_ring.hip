@@ -621,6 +621,17 @@ int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry)
       }
       if (geometry == 4) return launch_ring<4, 2, 2, 5, 2, 64, true, true>(p, s);
       if (geometry == 5) return launch_ring<4, 2, 2, 4, 2, 64, true, true>(p, s);
+      // round 4: the 4-wave geometries with 64-deep K tiles too (two LDS slots, one barrier per 64 columns instead of per 32): the deep
+      // UNet levels run few, long K loops per CU, where the per-K-tile latency (barrier + counted wait + fragment reads) is the kernel
+      if (geometry == 20) {
+        int rc = launch_splitk<2, 2, 2, 2, 2, false, 512, true, 64>(p, s);
+        if (rc >= 0) return rc;
+        geometry = 0;
+      }
+      if (geometry == 0 || geometry == 1) return launch_ring<2, 2, 2, 2, 2, 64, false, true>(p, s);
+      if (geometry == 2) return launch_ring<4, 1, 2, 5, 2, 64, false, true>(p, s);
+      if (geometry == 3) return launch_ring<4, 1, 2, 4, 2, 64, false, true>(p, s);
+      if (geometry == 12) return launch_ring<2, 2, 2, 5, 2, 64, false, true>(p, s);
     }
     geometry += 100;
   }

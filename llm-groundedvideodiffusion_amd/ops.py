@@ -74,10 +74,10 @@ class ConvGeom:
 # (M, N, K, loader): short-K linears favour many small workgroups, long-K convs the LDS-DMA ring, and the
 # 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
-GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117, 211)  # 100 + v: asm-DMA instantiation of ring variant v; 200 + v: 64-deep K tiles
+GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117, 211, 205, 209, 217)  # 100 + v: asm-DMA instantiation of ring variant v; 200 + v: 64-deep K tiles
 SPLITK_VARIANT = 20
 SPLITK_WIDE_VARIANT = 25
-TAIL_VARIANTS = (31, 37, 120, 125, 131, 137, 225, 231)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
+TAIL_VARIANTS = (31, 37, 120, 125, 131, 137, 225, 231, 220)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
 HALO_VARIANTS = (41, 45, 47)  # conv_halo.hip: whole grid / channel-chunk split-K / whole rounds + split-K tail
 _splitk_ws = {}
 

@@ -400,7 +400,7 @@ def _ln_fold_operands(W, bias, gamma, beta):
     return Wp, Wp.float().sum(1).contiguous(), ((bias if bias is not None else 0) + W.float() @ beta).contiguous()
 
 
-@pytest.mark.parametrize("variant", [0, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231, 20, 25])
+@pytest.mark.parametrize("variant", [0, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231, 20, 25, 205, 209, 217, 220])
 @pytest.mark.parametrize("M,N,K", [(700, 320, 320), (3000, 960, 640), (513, 2560, 320)])
 def test_gemm_layernorm_fold(variant, M, N, K):
     """LayerNorm(x) W^T + b as ONE product on the raw rows (lvd_gemm_params.ln_mean_rstd): every asm-DMA ring geometry and the K-split
@@ -421,7 +421,7 @@ def test_gemm_layernorm_fold(variant, M, N, K):
     except RuntimeError as e:
         # a K-split plan that decides not to split (short K, well-filled grid) degenerates to the builtin-DMA ring, which has no folded
         # epilogue: an error the autotuner skips over, never a silently un-normalised product
-        assert variant in (20, 25) and "LayerNorm-folded" in str(e), e
+        assert variant in (20, 25, 120, 220) and "LayerNorm-folded" in str(e), e
         return
     close(out, ref, 8e-3, f"v{variant} layernorm fold")
     # the folded product equals the two-launch path (LayerNorm kernel, then the plain product) to bf16 rounding
@@ -508,9 +508,19 @@ def test_gemm_k64_ring(M, N, K):
             assert torch.equal(out, ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=111)), "64-deep and 32-deep rings differ"
         for rep in range(3):
             assert torch.equal(out, ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=v)), f"v{v} run-to-run difference (race)"
+    # round 4: the 4-wave geometries with 64-deep tiles (128x128, 256x160 / 256x128, 128x320, K-split 128x128): same K order per
+    # accumulator as their 32-deep forms -> bit-equal to them; repeated launches bit-equal (the loop is the lock-step ring's, two slots)
+    for v64, v32 in ((205, 105), (209, 109), (217, 117), (220, 120)):
+        out = ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=v64)
+        close(out, ref, 6e-3, f"v{v64} {M}x{N}x{K}")
+        if v64 != 220:  # the K-split plans may pick other slice counts for the two ring depths
+            assert torch.equal(out, ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=v32)), f"v{v64} and v{v32} differ"
+        for rep in range(3):
+            assert torch.equal(out, ops.gemm(a, w, bias=bias, res=res, alpha=0.5, variant=v64)), f"v{v64} run-to-run difference (race)"
     a1, a2 = a[:, :K - 64].contiguous(), a[:, K - 64:].contiguous()
     if K > 128:
         close(ops.gemm(a1, w, a2=a2, bias=bias, variant=211), a.float() @ w.float().T + bias, 6e-3, f"v211 two sources {M}x{N}x{K}")
+        close(ops.gemm(a1, w, a2=a2, bias=bias, variant=205), a.float() @ w.float().T + bias, 6e-3, f"v205 two sources {M}x{N}x{K}")
     with pytest.raises(RuntimeError):
         ops.gemm(a, w, variant=141)  # a code that names no geometry is an error, not a silent fallback
 
@@ -630,7 +640,7 @@ def test_gemm_bit_reproducible_next_to_a_cotenant_process():
         M, N, K = 69120, 1536, 512
         a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
         bias = rnd(N, seed=3)
-        for v in (11, 111, 131, 211, 231, 225):
+        for v in (11, 111, 131, 211, 231, 225, 205, 209, 217):
             ref = ops.gemm(a, w, bias=bias, variant=v)
             for rep in range(12):
                 assert torch.equal(ops.gemm(a, w, bias=bias, variant=v), ref), f"variant {v}: launch {rep} differs from the first one"
