@@ -345,6 +345,11 @@ int lvdhip_tokens_grad_to_latents(const lvd_bf16* tokens, int32_t ld, float* lat
 /* y = a + b (bf16) ; gradient accumulation and residual adds */
 int lvdhip_add(const lvd_bf16* a, int32_t lda, const lvd_bf16* b, int32_t ldb, lvd_bf16* y, int32_t ldy,
                int32_t rows, int32_t c, void* stream);
+/* Temporal (3,1,1) conv at small M as an N-expanded plain product + combine (models/unet_3d_blocks.py:195-199 via diffusers' TemporalConvLayer):
+ * y [rows, 3n] fp32 = x . [W_0; W_1; W_2]^T from lvdhip_gemm; out[m] = bias + res[m] + y[m - hw, 0:n] + y[m, n:2n] + y[m + hw, 2n:3n] with the
+ * out-of-clip taps dropped (frame of row m = (m / hw) % frames). */
+int lvdhip_tconv_combine(const float* y, int32_t ldy, const float* bias, const lvd_bf16* res, int32_t ldres, lvd_bf16* out, int32_t ldo,
+                         int32_t rows, int32_t n, int32_t frames, int32_t hw, int32_t accumulate, void* stream);
 /* GEGLU pieces for the recorded (guidance) pass: pre = [hidden | gate] interleaved as the GEMM emits them */
 int lvdhip_geglu_fwd(const lvd_bf16* pre, int32_t ldp, lvd_bf16* y, int32_t ldy, int32_t rows, int32_t n_out,
                      void* stream);

@@ -66,6 +66,42 @@ __global__ void add_kernel(const lvd_bf16* a, int lda, const lvd_bf16* b, int ld
   }
 }
 
+// Temporal (3,1,1) convolution as an N-expanded product + this combine (engine._tconv, small M): Y[m, t*N + n] = x[m] . W_t[n] for the three
+// taps at once (a plain-loader GEMM with 3N output columns: three times the tiles, no K split), then
+//   out[m, n] = bias[n] + res[m, n] + Y[m - hw, n] (frame > 0) + Y[m, N + n] + Y[m + hw, 2N + n] (frame < F - 1),   summed in fp32 in tap order.
+__global__ void tconv_combine_kernel(const float* y, int ldy, const float* bias, const lvd_bf16* res, int ldres, lvd_bf16* out, int ldo,
+                                     int rows, int n, int frames, int hw, int accumulate) {
+  const int vpr = n >> 2;
+  const long tot = (long)rows * vpr;
+  GRID_STRIDE(i, tot) {
+    const long row = i / vpr;
+    const int c = (int)(i - row * vpr) * 4;
+    const int f = (int)((row / hw) % frames);
+    // clamped addresses + masks instead of branches around the loads
+    const long rp = f > 0 ? row - hw : row, rn = f < frames - 1 ? row + hw : row;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(y + rp * ldy + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(y + row * ldy + n + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(y + rn * ldy + 2 * n + c);
+    f32x4 v = (f > 0 ? 1.f : 0.f) * a;
+    v += b;
+    v += (f < frames - 1 ? 1.f : 0.f) * d;
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+    if (res) {
+      const uint2 r = ldg8(res + row * ldres + c);
+      v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+    }
+    lvd_bf16* o = out + row * ldo + c;
+    if (accumulate) {
+      const uint2 r = ldg8(o);
+      v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
+    }
+    uint2 w;
+    w.x = pack2bf(v[0], v[1]);
+    w.y = pack2bf(v[2], v[3]);
+    stg8(o, w);
+  }
+}
+
 // pre: [rows, 2*n_out] with hidden/gate interleaved in blocks of 32 (the GEMM's W' row order)
 __global__ void geglu_fwd_kernel(const lvd_bf16* pre, int ldp, lvd_bf16* y, int ldy, int rows, int n_out) {
   int vpr = n_out >> 2;
@@ -301,6 +337,15 @@ extern "C" int lvdhip_add(const lvd_bf16* a, int32_t lda, const lvd_bf16* b, int
   LVD_CHECK(a && b && y && c % 8 == 0, "add: bad args");
   long n = (long)rows * (c / 8);
   hipLaunchKernelGGL(add_kernel, dim3(nblocks(n)), dim3(256), 0, ST, a, lda, b, ldb, y, ldy, rows, c);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int lvdhip_tconv_combine(const float* y, int32_t ldy, const float* bias, const lvd_bf16* res, int32_t ldres, lvd_bf16* out, int32_t ldo,
+                                    int32_t rows, int32_t n, int32_t frames, int32_t hw, int32_t accumulate, void* stream) {
+  LVD_CHECK(y && out && n % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && (!res || ldres % 4 == 0), "tconv_combine: bad args");
+  LVD_CHECK(frames >= 1 && hw >= 1 && rows % (frames * hw) == 0, "tconv_combine: rows %d is not a multiple of frames * hw = %d", rows, frames * hw);
+  long tot = (long)rows * (n / 4);
+  hipLaunchKernelGGL(tconv_combine_kernel, dim3(nblocks(tot)), dim3(256), 0, ST, y, ldy, bias, res, ldres, out, ldo, rows, n, frames, hw, accumulate);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -124,6 +124,7 @@ class HipUNet3D:
         # classifier-free guidance: the part of the network in front of the first text-dependent layer once per sample (forward(cfg_pairs=True));
         # LVD_CFG_SHARED_PREFIX=0 makes the callers feed the duplicated batch like the reference does (A/B knob)
         self.cfg_shared_prefix = os.environ.get("LVD_CFG_SHARED_PREFIX", "1") != "0"
+        self.tconv_expand_max_rows = int(os.environ.get("LVD_TCONV_EXPAND_MAX_ROWS", "4320"))  # 0: every temporal conv on the tap GEMM
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -312,15 +313,33 @@ class HipUNet3D:
             tape.push(bw)
         return out, Geom(g_in.B, g_in.F, H2, W2)
 
+    def _tconv_weight_expanded(self, name, backward):
+        """[3N, Cin] form of a temporal-conv weight (ops.tconv_expand_weight) for the small-M path; built once, kept resident."""
+        key = (name, "tconv_exp_bwd" if backward else "tconv_exp")
+        t = self._dgrad.get(key)
+        if t is None:
+            t = self._dgrad[key] = ops.tconv_expand_weight(self.wt(name, "tconv") if backward else self.w[name])
+        return t
+
     def _tconv(self, x, name, g: Geom, *, tape, res=None):
-        out = ops.gemm(x, self.w[name + ".weight"], bias=self.w[name + ".bias"], res=res, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
+        # Deep levels (<= tconv_expand_max_rows token rows): the tap GEMM has 3 - 9 tiles of 512 rows there and runs as a K-split launch whose
+        # fp32 slabs (padded to whole tiles) outweigh the product; ONE plain product with 3N columns + a combine pass is faster
+        # (tools/deep_probe.py: 42.0 -> 34.6 us at 1080 rows, 53.4 -> 41.7 at 2160, 68.8 -> 65.5 at 4320; slower from 8640 rows on).
+        small = x.shape[0] <= self.tconv_expand_max_rows
+        if small:
+            out = ops.tconv_expanded(x, self._tconv_weight_expanded(name + ".weight", False), frames=g.F, hw=g.HW, bias=self.w[name + ".bias"], res=res)
+        else:
+            out = ops.gemm(x, self.w[name + ".weight"], bias=self.w[name + ".bias"], res=res, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
         if tape is not None:
             def bw():
                 dy = tape.pop(out)
                 if dy is None:
                     return
                 buf, acc = tape.target(x)
-                ops.gemm(dy, self.wt(name + ".weight", "tconv"), out=buf, accumulate=acc, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
+                if small:
+                    ops.tconv_expanded(dy, self._tconv_weight_expanded(name + ".weight", True), frames=g.F, hw=g.HW, out=buf, accumulate=acc)
+                else:
+                    ops.gemm(dy, self.wt(name + ".weight", "tconv"), out=buf, accumulate=acc, mode=ops.A_TCONV3, frames=g.F, hw=g.HW)
                 if res is not None:
                     tape.accumulate(res, dy)
             tape.push(bw)

@@ -164,6 +164,7 @@ SYMBOLS = {
     "lvdhip_tokens_to_latents": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, C.c_void_p],
     "lvdhip_tokens_grad_to_latents": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, f32, C.c_void_p],
     "lvdhip_add": [C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
+    "lvdhip_tconv_combine": [C.c_void_p, i32, C.c_void_p, C.c_void_p, i32, C.c_void_p, i32, i32, i32, i32, i32, i32, C.c_void_p],
     "lvdhip_geglu_fwd": [C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
     "lvdhip_geglu_bwd": [C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, i32, i32, C.c_void_p],
     "lvdhip_upsample2x_bwd": [C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p],

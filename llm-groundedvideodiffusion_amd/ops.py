@@ -400,6 +400,26 @@ def layernorm(x, gamma, beta, *, eps=1e-5, out=None, return_stats=False):
     return (out, mr) if return_stats else out
 
 
+def tconv_expand_weight(wt, taps=3):
+    """[N, taps * Cin] tap-major temporal-conv weight -> [taps * N, Cin]: row t * N + n holds tap t of output channel n (tconv_expanded)."""
+    n, k = wt.shape
+    return wt.view(n, taps, k // taps).permute(1, 0, 2).reshape(taps * n, k // taps).contiguous()
+
+
+def tconv_expanded(x, w_exp, *, frames, hw, bias=None, res=None, out=None, accumulate=False):
+    """Temporal (3,1,1) conv as ONE plain product with 3N output columns (fp32) + a combine pass: for small M (deep UNet levels) three times
+    the tiles and no K split beat the tap GEMM's K-split slabs.  `w_exp` = tconv_expand_weight(w)."""
+    _chk_bf16(x, w_exp, res)
+    m, n = x.shape[0], w_exp.shape[0] // 3
+    y = gemm(x, w_exp, out_fp32=True)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+        assert not accumulate
+    hip.check(hip.lib().lvdhip_tconv_combine(_p(y), _ld(y), _p(bias), _p(res), _ld(res) if res is not None else 0, _p(out), _ld(out), m, n, frames, hw,
+                                             int(accumulate), _stream()), "tconv_combine")
+    return out
+
+
 def layernorm_stats(x, *, eps=1e-5):
     """(mean, rstd) [rows, 2] fp32 of every row — what a LayerNorm-folded GEMM (gemm(..., ln_stats=)) and layernorm_bwd read; x is only read."""
     _chk_bf16(x)

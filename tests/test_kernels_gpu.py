@@ -184,6 +184,13 @@ def test_tconv3():
     res = bf(rnd(B * Fr * hw, cout, seed=4))
     out = ops.gemm(x, wp, bias=b, mode=ops.A_TCONV3, frames=Fr, hw=hw, res=res)
     close(out, ref_tok + res.float(), 6e-3, "tconv3")
+    # the small-M form of the engine: one plain product with 3N columns (fp32) + the combine pass; also accumulating (the dgrad's use)
+    we = ops.tconv_expand_weight(wp)
+    close(ops.tconv_expanded(x, we, frames=Fr, hw=hw, bias=b, res=res), ref_tok + res.float(), 6e-3, "tconv3 expanded + combine")
+    acc = bf(rnd(B * Fr * hw, cout, seed=5))
+    want = acc.float() + (ref_tok - b)
+    ops.tconv_expanded(x, we, frames=Fr, hw=hw, out=acc, accumulate=True)
+    close(acc, want, 6e-3, "tconv3 expanded, accumulate")
 
 
 # ----------------------------------------------------------------------------- norms

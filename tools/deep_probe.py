@@ -57,3 +57,17 @@ for M, hw, h, w in ((1080, 45, 5, 9), (2160, 45, 5, 9), (4320, 180, 10, 18), (86
         var = {k[0]: ops.gemm_autotune_table()[k] for k in key}
         print(f"{kind:5s} M={M:5d} K={K:5d}: today {t_cur:6.1f} us {fl / t_cur / 1e6:5.0f} TF/s | plain GEMM on a materialised im2col {t_plain:6.1f} us "
               f"{fl / t_plain / 1e6:5.0f} TF/s (+ {2 * M * K * 2 / 1e6:.0f} MB of im2col traffic if materialised) variants {var}", flush=True)
+
+print("# temporal conv: tap GEMM / K-split plan of the step vs N-expanded plain product (3N columns, fp32) + combine pass")
+for M, hw in ((1080, 45), (2160, 45), (4320, 180), (8640, 180), (17280, 720), (34560, 720)):
+    cin = cout = 1280 if hw <= 180 else 640
+    x = rnd(M, cin)
+    wt = rnd(cout, 3 * cin) * 0.02
+    bias = torch.randn(cout, device=dev)
+    res = rnd(M, cout)
+    we = ops.tconv_expand_weight(wt)
+    cur = lambda: ops.gemm(x, wt, bias=bias, res=res, mode=ops.A_TCONV3, frames=F, hw=hw)
+    new = lambda: ops.tconv_expanded(x, we, frames=F, hw=hw, bias=bias, res=res)
+    err = ((new().float() - cur().float()).norm() / cur().float().norm()).item()
+    t0, t1 = timeit(cur), timeit(new)
+    print(f"tconv M={M:6d} C={cin:4d}: tap GEMM {t0:6.1f} us | expanded + combine {t1:6.1f} us  (rel diff {err:.1e})", flush=True)
