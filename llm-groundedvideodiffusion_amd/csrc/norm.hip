@@ -9,6 +9,7 @@
 // thread owns 8 channels; the channels of a group are folded inside the workgroup), and the APPLY kernel folds the
 // chunks of its sample itself (fixed order, a few KB from L2 per workgroup) — there is no finalize launch between
 // the two passes (round 3: 2328 launches of 5.7 us per 8 steps that did nothing else).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -579,7 +580,8 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const lvd_ln_bwd_param
 // row chunks per sample for the elementwise passes: ~3 workgroups per CU over the whole launch (one resident round: every workgroup
 // of a sample repeats the fold of its statistics partials, so few fat workgroups beat many thin ones), >= 4 rows per row lane
 int gn_row_chunks(int samples, int rows_per_sample, int RL) {
-  int want = (768 + samples - 1) / samples;
+  static const int target = [] { const char* e = getenv("LVD_GN_APPLY_WGS"); return e ? atoi(e) : 768; }();  // developer knob
+  int want = (target + samples - 1) / samples;
   if (want > 512) want = 512;
   int most = rows_per_sample / (4 * RL);
   if (want > most) want = most;

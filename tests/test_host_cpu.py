@@ -279,7 +279,7 @@ def test_gemm_autotune_table_round_trip(tmp_path):
 def test_groupnorm_chunking_rules():
     """Statistics chunks: enough workgroups for 256 CUs, never fewer than the minimum rows per chunk, never zero."""
     from lvd_amd import ops
-    assert ops._gn_chunks(48, 2880) == 16            # level 0, 2-D norm: 768 // 48
+    assert ops._gn_chunks(48, 2880) == 10            # level 0, 2-D norm: 512 // 48
     assert ops._gn_chunks(2, 69120) == 256           # level 0, 5-D norm: capped (the apply workgroups fold the chunk partials themselves)
     assert ops._gn_chunks(2, 1080) == 16             # 5x9 level, forward: 64-row chunks
     assert ops._gn_chunks(2, 1080, 32) == 33         # ... backward statistics: 32-row chunks
