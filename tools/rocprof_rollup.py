@@ -13,7 +13,7 @@ CLASSES = [
     ("attention fwd/bwd", ("attn_",)),
     ("LayerNorm", ("ln_",)),
     ("guidance loss (3 kernels/key)", ("ca_",)),
-    ("elementwise / layout", ("geglu_", "add_kernel", "silu_kernel", "tokens", "upsample2x", "timestep_embedding", "cfg_dpm", "axpy", "reduce_sum")),
+    ("elementwise / layout (incl. the temporal-conv combine pass)", ("geglu_", "add_kernel", "silu_kernel", "tokens", "upsample2x", "timestep_embedding", "cfg_dpm", "axpy", "reduce_sum", "tconv_combine")),
 ]
 
 
