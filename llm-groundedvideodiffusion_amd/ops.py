@@ -228,13 +228,14 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     return out
 
 
-GN_MAX_CHUNKS = int(os.environ.get("LVD_GN_MAX_CHUNKS", "256"))
+GN_MAX_CHUNKS = int(os.environ.get("LVD_GN_MAX_CHUNKS", "256"))  # developer knobs (tools/small_ops_bench.py sweeps): chunks per sample ...
+GN_STATS_WGS = int(os.environ.get("LVD_GN_WGS", "512"))           # ... and workgroups per statistics launch
 
 
 def _gn_chunks(samples, rows_per_sample, min_rows=64):
     # two workgroups per CU over the whole launch (measured best: 512 against 768 / 1024, tools/small_ops_bench.py), but >= min_rows rows per chunk, and at most GN_MAX_CHUNKS per sample: every
     # workgroup of the apply pass folds the [chunks, groups] partials of its sample itself (no finalize launch), 8 bytes * groups per chunk
-    want = max(1, min(int(os.environ.get("LVD_GN_WGS", "512")) // max(samples, 1), GN_MAX_CHUNKS))
+    want = max(1, min(GN_STATS_WGS // max(samples, 1), GN_MAX_CHUNKS))
     return max(1, min(want, rows_per_sample // min_rows if rows_per_sample >= min_rows else 1))
 
 
