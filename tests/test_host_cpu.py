@@ -55,8 +55,14 @@ def test_shipped_gemm_autotune_table_is_loadable():
         tab = ops.gemm_autotune_table()
         assert len(tab) >= 150
         known = set(ops.GEMM_CANDIDATES) | {ops.SPLITK_VARIANT, ops.SPLITK_WIDE_VARIANT} | set(ops.TAIL_VARIANTS) | set(ops.HALO_VARIANTS)
+        folded = 0
         for k, v in tab.items():
-            assert len(k) == 14 and v in known, (k, v)
+            assert len(k) in (14, 15) and v in known, (k, v)
+            if len(k) == 15:  # a LayerNorm-folded product (round 4): plain loader, asm-DMA ring or K-split variants only
+                folded += 1
+                assert k[14] is True and k[0] == ops.A_PLAIN and (v >= 100 or v in (ops.SPLITK_VARIANT, ops.SPLITK_WIDE_VARIANT)), (k, v)
+        assert folded >= 20
+        for k, v in tab.items():
             assert k[0] in (ops.A_PLAIN, ops.A_CONV3X3, ops.A_TCONV3, ops.A_CONV3X3_T2) and (k[7] is None or len(k[7]) == 4)
         # the headline shapes are in it: level-0 QKV projection of the CFG batch and the level-0 resnet conv
         assert any(k[:4] == (ops.A_PLAIN, 138240, 960, 320) for k in tab) and any(k[:4] == (ops.A_CONV3X3, 138240, 320, 2880) for k in tab)
