@@ -21,8 +21,8 @@ def test_plain_bench_command_self_launches_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
                         "--unguided-steps", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]  # stdout IS the one JSON line (library banners of the ranks go to stderr)
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks_seen"]["world_size"] == 2 and j["rccl_ranks_seen"]["ranks"] == [0, 1]
     assert j["scaling"] == "weak" and abs(j["value"] - 2 * 24 / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"]
