@@ -323,7 +323,9 @@ typedef struct {
 int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream);
 /* All keys of one guidance iteration (utils/guidance.py:529-574 loops over guidance_attn_keys) in ONE launch per stage instead of one per
  * key: `keys` is a host array of `nkeys` <= LVD_CA_MAX_KEYS parameter blocks, each exactly what the single-key entry point takes (its own
- * q / k / P / heads / buffers); blockIdx.z selects the key.  Same results, bit for bit, as nkeys single-key calls. */
+ * q / k / P / heads / buffers); the grid is flat over the keys' workgroups.  Same results, bit for bit, as nkeys single-key calls (which
+ * are the nkeys = 1 case of the same kernels).  Prompts of up to 96 text positions take the staged-key bodies (four query tiles per
+ * workgroup, keys read once into LDS); longer prompts the general one-wave bodies. */
 #define LVD_CA_MAX_KEYS 8
 int lvdhip_ca_probs_multi(const lvd_ca_probs_params* keys, int32_t nkeys, void* stream);
 int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t nkeys, void* stream);

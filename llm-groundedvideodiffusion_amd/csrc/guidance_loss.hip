@@ -46,6 +46,29 @@ LVD_DEV float dot8(uint4 a, uint4 b) {
          bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
 
+// The head's keys, row-major, staged once per 256-thread workgroup: 96 rows (positions past the prompt repeat its last row; their scores
+// are masked) of 64 channels, 144-byte row pitch (16-byte fragment reads of 16 consecutive rows hit 16 different bank groups).  Loaded
+// this way a key row is one cache line shared by eight lanes; as MFMA fragments straight from global memory every lane of a load touches
+// its own line, and each wave of the workgroup repeats the twelve loads.
+constexpr int KROW = 36;  // dwords
+struct KStage { uint4 v[3]; };
+LVD_DEV KStage kstage_load(const lvd_bf16* k, int ldk, int ntext, int h) {
+  KStage r;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int row = min(s * 32 + ((int)threadIdx.x >> 3), ntext - 1);
+    r.v[s] = ldg16(k + (long)row * ldk + h * 64 + (threadIdx.x & 7) * 8);
+  }
+  return r;
+}
+LVD_DEV void kstage_store(uint32_t* k_lds, const KStage& r) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s) *reinterpret_cast<uint4*>(k_lds + (s * 32 + ((int)threadIdx.x >> 3)) * KROW + (threadIdx.x & 7) * 4) = r.v[s];
+}
+LVD_DEV bf16x8 kstage_frag(const uint32_t* k_lds, int kt, int ks, int l31, int hi) {
+  return as_bf16x8(*reinterpret_cast<const uint4*>(k_lds + (kt * 32 + l31) * KROW + ks * 8 + hi * 4));
+}
+
 // ------------------------------------------------------------------------------------ 1. probs
 // grid (frames * ceil(P/32), heads), one wave per 32-query tile
 LVD_DEV void ca_probs_body(const lvd_ca_probs_params& p, const int bx, const int by) {
@@ -97,6 +120,68 @@ LVD_DEV void ca_probs_body(const lvd_ca_probs_params& p, const int bx, const int
   }
 }
 
+// Prompts of up to 96 text positions (three 32-key tiles; CLIP has 77).  A wave here is bound by latency and by the load path, not by
+// HBM: the general body re-reads the head's keys tile by tile and then once more, row by row, for the object tokens (28 KB of L2 reads
+// for 4 KB of queries).  Here every global load of the wave — the query rows and the twelve key fragments — is issued before the first
+// MFMA (one memory round trip), and the object tokens' scores are taken from the S tiles the MFMAs already produced instead of being
+// recomputed from re-loaded key rows.  Same result as ca_probs_body up to summation order (the token scores are the MFMA's fp32 sums).
+LVD_DEV void ca_probs_body3(const lvd_ca_probs_params& p, const int bx, const int by) {
+  __shared__ uint32_t k_lds[96 * KROW];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.P + 31) >> 5;
+  const bool live = bx < nqt * p.frames;
+  const int bxc = live ? bx : nqt * p.frames - 1;
+  const int f = bxc / nqt, qt = bxc - f * nqt, h = by;
+  const int qi = qt * 32 + l31;
+  const int qic = min(qi, p.P - 1);
+  const lvd_bf16* qp = p.q + ((long)f * p.P + qic) * p.ldq + h * 64 + hi * 8;
+  uint4 qraw[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qraw[ks] = ldg16(qp + ks * 16);
+  kstage_store(k_lds, kstage_load(p.k, p.ldk, p.ntext, h));
+  __syncthreads();
+  if (!live) return;
+  const float sc = p.scale * 1.4426950408889634f;
+  float v[3][16], m = -1e30f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kstage_frag(k_lds, kt, ks, l31, hi), as_bf16x8(qraw[ks]), st, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      v[kt][e] = kidx < p.ntext ? st[e] * sc : -1e30f;
+      m = fmaxf(m, v[kt][e]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float lsum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lsum += fast_exp2(v[kt][e] - m);
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float lse2 = m + log2f(lsum);
+  const long row = ((long)f * p.heads + h);
+  if (hi == 0 && qi < p.P) p.lse[row * p.P + qi] = lse2 * 0.6931471805599453f;
+  for (int t = 0; t < p.ntok; ++t) {
+    // score of text position tk for this lane's query: tile tk / 32, accumulator slot e with (e & 3) + 8 (e >> 2) + 4 hi = tk % 32,
+    // held by the half-wave hi = bit 2 of tk
+    const int tk = p.tok_ids[t], kt = tk >> 5, r = tk & 31;
+    float s = -1e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float cand = kt == 0 ? v[0][e] : (kt == 1 ? v[1][e] : v[2][e]);
+      s = ((e & 3) + 8 * (e >> 2) + 4 * hi == r) ? cand : s;
+    }
+    s = fmaxf(s, __shfl_xor(s, 32, 64));  // the other half-wave holds -1e30
+    if (hi == 0 && qi < p.P) p.probs[(row * p.ntok + t) * p.P + qi] = fast_exp2(s - lse2);
+  }
+}
+
 // ------------------------------------------------------------------------------------ 2a. centre of mass
 // grid frames*heads*ntok, block 256: com_ws[.,4] = (sum A, com_y, com_x, 0)
 LVD_DEV void ca_com_body(const lvd_ca_select_params& p, const int b) {
@@ -124,56 +209,88 @@ LVD_DEV void ca_com_body(const lvd_ca_select_params& p, const int b) {
 }
 
 // ------------------------------------------------------------------------------------ 2b. select
-// Exact k-th largest of 44-bit keys (value bits << 12 | (4095 - index)), for the entries inside the box (flag 1, k = k1) and outside
-// it (flag 0, k = k0) at once: six 8-bit passes, both histograms built in the same sweep, and the bin that holds the k-th largest found
-// by a 256-thread suffix scan (one bin per thread, top bin first) instead of a serial walk over the bins.  thr[w] = key of the k-th
-// largest of class w (entries with key >= thr[w] are its top-k set); a class with k <= 0 or no members keeps ~0 ("nothing selected").
-// blockDim.x must be 256.
-LVD_DEV void radix_select2(const float* vals, const unsigned char* flag, int n, int k0, int k1, bool on0, bool on1,
-                           unsigned int (*hist)[256], int (*sh)[2], int (*wtot)[4], unsigned long long thr[2]) {
+// One WAVE per (frame, head, token) map, four maps per workgroup, no workgroup barrier anywhere: the map (P <= 64 E values) lives in the
+// lanes' registers, entry i in lane i % 64.  [The first version gave each map a 256-thread workgroup; at P = 180 — four of the six
+// guidance keys — most of those threads had no entry and the kernel was bound by the instructions of its scans and barriers.]
+LVD_DEV void wave_lds_sync() {  // orders this wave's LDS (and, with the waitcnt the fences imply, global) accesses across its lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// Wave-wide inclusive scan on the DPP path (row shifts inside the rows of 16 lanes, then the two row broadcasts): six VALU operations.
+// __shfl_up goes through ds_bpermute, an LDS round trip per step — and this kernel is one long dependent chain per wave.
+LVD_DEV int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+LVD_DEV float dpp_add(float v, int moved) { return v + __int_as_float(moved); }
+LVD_DEV float wave_total(float v) {  // sum over the wave, same value in every lane
+  v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+  v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));
+  v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));
+  v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));
+  v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+  v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+LVD_DEV unsigned long long select_key(float a, int i) { return ((unsigned long long)__float_as_uint(a) << 12) | (unsigned)(4095 - i); }
+
+// Exact top-k sets by radix select on 44-bit keys (value bits << 12 | (4095 - index): ties go to the lowest index), for the entries inside
+// the box (class 1, k = k1) and outside it (class 0, k = k0) at once: 8-bit digits from the top, both histograms (hist[2][256], private to
+// the wave) built in the same sweep, the bin holding the k-th largest found by a suffix scan (four bins per lane, top bin first).  A class
+// stops as soon as the bin it lands in is wanted whole: every key sharing the prefix so far is then in the set, and `key >= prefix` (low
+// digits zero) selects exactly what the exact k-th key would — distinct float values leave a one-entry bin after two or three digits, so
+// the usual case is 3-4 sweeps, not 6.  thr[w]: entries of class w with key >= thr[w] are its top-k set; ~0 = nothing selected (k <= 0
+// or no members).  cls[j]: 0 / 1, or 2 for a lane slot past the end of the map.
+template <int E>
+LVD_DEV void radix_select2_wave(const float (&a)[E], const int (&cls)[E], int n, int lane, int k0, int k1, bool on0, bool on1, unsigned int* hist,
+                                unsigned long long thr[2]) {
   unsigned long long prefix[2] = {0, 0}, maskbits = 0;
   int need[2] = {k0, k1};
-  const bool on[2] = {on0, on1};
-  const int tb = threadIdx.x;
-  for (int pass = 5; pass >= 0; --pass) {
-    hist[0][tb] = 0;
-    hist[1][tb] = 0;
-    __syncthreads();
-    for (int i = tb; i < n; i += 256) {
-      const int w = flag[i];
-      if (!on[w]) continue;
-      const unsigned long long key = ((unsigned long long)__float_as_uint(vals[i]) << 12) | (unsigned)(4095 - i);
-      if ((key & maskbits) == prefix[w]) atomicAdd(&hist[w][(key >> (8 * pass)) & 255], 1u);
+  bool act[2] = {on0, on1};  // class still being refined (wave-uniform)
+  for (int pass = 5; pass >= 0 && (act[0] || act[1]); --pass) {
+    *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(hist + 256 + 4 * lane) = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      if (j * 64 >= n) break;  // wave-uniform: a short map in a kernel built for a longer one
+      const int w = cls[j];
+      if (w > 1 || !act[w]) continue;
+      const unsigned long long key = select_key(a[j], j * 64 + lane);
+      if ((key & maskbits) == prefix[w]) atomicAdd(&hist[w * 256 + (int)((key >> (8 * pass)) & 255)], 1u);
     }
-    __syncthreads();
-    int c[2], incl[2];
+    wave_lds_sync();
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-      c[w] = (int)hist[w][255 - tb];
-      incl[w] = c[w];
+      if (!act[w]) continue;
+      const uint4 c4 = *reinterpret_cast<const uint4*>(hist + w * 256 + 252 - 4 * lane);
+      const int c[4] = {(int)c4.w, (int)c4.z, (int)c4.y, (int)c4.x};  // c[q] = entries in bin 255 - (4 lane + q)
+      const int tot = c[0] + c[1] + c[2] + c[3];
+      int run = wave_scan_incl(tot) - tot, fbin = -1, frem = 0, fcnt = 0;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl[w], o, 64);
-        if ((tb & 63) >= o) incl[w] += v;
+      for (int q = 0; q < 4; ++q) {
+        const int above = run;
+        run += c[q];
+        // the first bin from the top whose running count reaches `need`; bin 0 takes whatever is left when the class has fewer members
+        if ((run >= need[w] && above < need[w]) || (lane == 63 && q == 3 && run < need[w])) { fbin = 255 - (4 * lane + q); frem = need[w] - above; fcnt = c[q]; }
       }
-      if ((tb & 63) == 63) wtot[w][tb >> 6] = incl[w];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      for (int q = 0; q < (tb >> 6); ++q) incl[w] += wtot[w][q];
-      const int excl = incl[w] - c[w];
-      // the first bin from the top whose running count reaches `need` (bin 0 takes whatever is left, as the serial walk did)
-      if ((incl[w] >= need[w] && excl < need[w]) || (tb == 255 && incl[w] < need[w])) {
-        sh[w][0] = 255 - tb;
-        sh[w][1] = need[w] - excl;
+      const unsigned long long hit = __ballot(fbin >= 0);
+      if (hit == 0) {  // k <= 0
+        act[w] = false;
+        prefix[w] = ~0ull;
+        continue;
       }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      prefix[w] |= (unsigned long long)sh[w][0] << (8 * pass);
-      need[w] = sh[w][1];
+      const int src = __ffsll((long long)hit) - 1;
+      fbin = __builtin_amdgcn_readlane(fbin, src); frem = __builtin_amdgcn_readlane(frem, src); fcnt = __builtin_amdgcn_readlane(fcnt, src);
+      prefix[w] |= (unsigned long long)fbin << (8 * pass);
+      need[w] = frem;
+      if (frem == fcnt) act[w] = false;
     }
     maskbits |= 0xffull << (8 * pass);
   }
@@ -181,15 +298,12 @@ LVD_DEV void radix_select2(const float* vals, const unsigned char* flag, int n, 
   thr[1] = on1 ? prefix[1] : ~0ull;
 }
 
-LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
-  extern __shared__ unsigned char smem[];
-  float* vals = reinterpret_cast<float*>(smem);                         // [P]
-  unsigned char* flag = smem + (size_t)p.P * 4;                         // [P] 1 = inside the box
-  __shared__ unsigned int hist[2][256];
-  __shared__ int sh[2][2];
-  __shared__ int wtot[2][4];
-  __shared__ float red[8];
-
+// ws: this wave's LDS: hist[512] then vals[P] (only the BoxDiff term reads the map back by position)
+template <int E>
+LVD_DEV void ca_select_wave(const lvd_ca_select_params& p, const int b, unsigned int* ws) {
+  unsigned int* hist = ws;
+  float* vals = reinterpret_cast<float*>(ws + 512);
+  const int lane = threadIdx.x & 63;
   const int t = b % p.ntok;
   const int fh = b / p.ntok;
   const int h = fh % p.heads, f = fh / p.heads;
@@ -201,19 +315,29 @@ LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
   float* dA = p.dprobs + (long)b * p.P;
   const float wt = p.tok_weight[t];
   const float c = p.grad_scale * wt;
+  const bool boxdiff = p.boxdiff_loss_scale > 0.f;
+  (void)h;
 
-  for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
-    int y = i / p.W, x = i - y * p.W;
-    vals[i] = A[i];
-    flag[i] = (y >= y0 && y < y1 && x >= x0 && x < x1) ? 1 : 0;
+  float a[E];
+  int cls[E];  // 1 = inside the box, 0 = outside, 2 = past the end of the map
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = j * 64 + lane;
+    const bool valid = i < p.P;
+    a[j] = 0.f;
+    cls[j] = 2;
+    if (j * 64 >= p.P) continue;  // wave-uniform
+    a[j] = valid ? A[i] : 0.f;
+    const int y = i / p.W, x = i - y * p.W;
+    cls[j] = !valid ? 2 : ((y >= y0 && y < y1 && x >= x0 && x < x1) ? 1 : 0);
+    if (boxdiff && valid) vals[i] = a[j];
   }
-  __syncthreads();
 
   unsigned long long thr_fg = ~0ull, thr_bg = ~0ull;  // "nothing selected"
   const bool ratio = p.use_ratio_loss != 0;
   if (!ratio) {
     unsigned long long thr[2];
-    radix_select2(vals, flag, p.P, kbg, kfg, p.P - nmask > 0, nmask > 0, hist, sh, wtot, thr);
+    radix_select2_wave<E>(a, cls, p.P, lane, kbg, kfg, p.P - nmask > 0, nmask > 0, hist, thr);
     thr_bg = thr[0];
     thr_fg = thr[1];
   }
@@ -221,12 +345,9 @@ LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
   float r_in = 0.f, r_out = 0.f, ratio_loss = 0.f;  // dL/dA[p] = r_in inside the box, r_out outside
   if (ratio) {
     float sa = 0.f, sm = 0.f;
-    for (int i = threadIdx.x; i < p.P; i += blockDim.x) { sa += vals[i]; sm += flag[i] ? vals[i] : 0.f; }
-    sa = wave_sum(sa); sm = wave_sum(sm);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[4 + (threadIdx.x >> 6)] = sm; }
-    __syncthreads();
-    sa = red[0] + red[1] + red[2] + red[3]; sm = red[4] + red[5] + red[6] + red[7];
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < E; ++j) { sa += a[j]; sm += cls[j] == 1 ? a[j] : 0.f; }
+    sa = wave_total(sa); sm = wave_total(sm);
     const float den = sa + p.ratio_eps, act = sm / den;
     ratio_loss = (1.f - act) * (1.f - act) / (float)p.heads;
     const float k2 = -2.f * (1.f - act) / ((float)p.heads * den * den);
@@ -234,7 +355,7 @@ LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
     r_out = k2 * (-sm);
   }
   // attention sync (:401-430).  The reference crops BOTH frames with the box of the NEXT frame (its x_min..y_max were
-  // overwritten by the t1 loop), per head: w * mean_box((A_f - A_f+1)^2).  This block owns frame f: the pair (f, f+1) with
+  // overwritten by the t1 loop), per head: w * mean_box((A_f - A_f+1)^2).  This wave owns frame f: the pair (f, f+1) with
   // box(f+1), and — as the second frame of the pair (f-1, f) — the gradient that pair sends to frame f, cropped with box(f).
   // An empty next-frame box is a NaN in the reference (mean of an empty crop); here the pair contributes nothing.
   const float sw = p.attn_sync_weight;
@@ -290,50 +411,47 @@ LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
 
   float sfg = 0.f, sbg = 0.f, ssync = 0.f;
   const float gfg = -p.fg_weight / (float)kfg, gbg = p.bg_weight / (float)kbg;
-  for (int i = threadIdx.x; i < p.P; i += blockDim.x) {
-    float a = vals[i];
-    unsigned long long key = ((unsigned long long)__float_as_uint(a) << 12) | (unsigned)(4095 - i);
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = j * 64 + lane;
+    if (j * 64 >= p.P) break;  // wave-uniform
+    if (cls[j] > 1) continue;
+    const float av = a[j];
+    const unsigned long long key = select_key(av, i);
     float g = 0.f;
     if (ratio) {
-      g += flag[i] ? r_in : r_out;
-    } else if (flag[i]) {
-      if (key >= thr_fg) { sfg += a; g += gfg; }
+      g += cls[j] ? r_in : r_out;
+    } else if (cls[j]) {
+      if (key >= thr_fg) { sfg += av; g += gfg; }
     } else {
-      if (key >= thr_bg) { sbg += a; g += gbg; }
+      if (key >= thr_bg) { sbg += av; g += gbg; }
     }
     const int y = i / p.W, x = i - y * p.W;
     if (gy != 0.f || gx != 0.f) g += (gy * ((float)y - cy) + gx * ((float)x - cx)) / S;
     if (Anext && y >= ny0 && y < ny1 && x >= nx0 && x < nx1) {
-      const float d = a - Anext[i];
+      const float d = av - Anext[i];
       ssync += d * d;
       g += 2.f * snext * d;
     }
-    if (Aprev && flag[i]) g -= 2.f * sprev * (Aprev[i] - a);
+    if (Aprev && cls[j]) g -= 2.f * sprev * (Aprev[i] - av);
     dA[i] = c * g;
   }
-  sfg = wave_sum(sfg); sbg = wave_sum(sbg); ssync = wave_sum(ssync);
-  int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[w] = sfg; red[4 + w] = sbg; }
-  __syncthreads();
-  const float tf = red[0] + red[1] + red[2] + red[3], tb = red[4] + red[5] + red[6] + red[7];
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = ssync;
-  __syncthreads();
-  const float tsync = red[0] + red[1] + red[2] + red[3];
+  const float tf = wave_total(sfg), tb = wave_total(sbg), tsync = wave_total(ssync);
   float loss = ratio ? ratio_loss : p.fg_weight * (1.f - tf / (float)kfg) + p.bg_weight * (tb / (float)kbg);
   loss += com_loss + snext * tsync;
 
   // BoxDiff corner constraint (:240-287, 433-465): |max over rows/columns of A - max of the mask| on the corner columns/rows;
-  // the gradient goes to the (first) arg-max of each column / row.  dA was written above: the adds below are ordered by barriers.
-  if (p.boxdiff_loss_scale > 0.f) {
+  // the gradient goes to the (first) arg-max of each column / row.  dA was written above by other lanes of this wave: the adds below
+  // come behind a wave-level fence, and so does the second pass (a cell can be the arg-max of its column and of its row).
+  if (boxdiff) {
     const int L = p.boxdiff_L, Hh = p.H, Ww = p.W;
     float cc = 0.f;
-    __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {  // pass 0: columns (max over y), pass 1: rows (max over x)
+      wave_lds_sync();
       const int n = pass == 0 ? Ww : Hh, m = pass == 0 ? Hh : Ww;
       const int lo = pass == 0 ? x0 : y0, hi2 = pass == 0 ? x1 : y1;
       const float norm = p.boxdiff_normed ? 1.f / ((float)p.heads * (float)n) : 1.f;
-      for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      for (int j = lane; j < n; j += 64) {
         const bool corner = (j >= max(lo - L, 0) && j < min(lo + L + 1, n)) || (j >= max(hi2 - L, 0) && j < min(hi2 + L + 1, n));
         if (!corner) continue;
         float best = -1.f;
@@ -348,17 +466,61 @@ LVD_DEV void ca_select_body(const lvd_ca_select_params& p, const int b) {
         const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
         dA[arg] += c * p.boxdiff_loss_scale * norm * sg;
       }
-      __syncthreads();
     }
-    cc = wave_sum(cc);
-    if ((threadIdx.x & 63) == 0) red[w] = cc;
-    __syncthreads();
-    loss += p.boxdiff_loss_scale * (red[0] + red[1] + red[2] + red[3]);
+    loss += p.boxdiff_loss_scale * wave_total(cc);
   }
-  if (threadIdx.x == 0) p.loss_partial[b] = wt * loss;
+  if (lane == 0) p.loss_partial[b] = wt * loss;
 }
 
 // ------------------------------------------------------------------------------------ 3. dQ
+LVD_DEV void ca_dq_store(const lvd_ca_dq_params& p, int f, int qi, int h, int hi, const f32x16& dq0, const f32x16& dq1) {
+  if (p.acc_mode == 0) {
+    // The accumulator holds, per query, channels {8 r + 4 hi .. + 3}: 8-byte pieces interleaved between the two half-waves.  The halves
+    // trade every other piece, so each lane stores 16 contiguous bytes and a store instruction covers half as many pieces of cache lines.
+    const float fs = p.scale;
+    lvd_bf16* op = p.dq + ((long)f * p.P + min(qi, p.P - 1)) * p.lddq + h * 64 + 8 * hi;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x16& d = blk ? dq1 : dq0;
+        uint2 lo, up;  // channels 16 m + 4 hi .. and 16 m + 8 + 4 hi ..
+        lo.x = pack2bf(d[8 * m + 0] * fs, d[8 * m + 1] * fs); lo.y = pack2bf(d[8 * m + 2] * fs, d[8 * m + 3] * fs);
+        up.x = pack2bf(d[8 * m + 4] * fs, d[8 * m + 5] * fs); up.y = pack2bf(d[8 * m + 6] * fs, d[8 * m + 7] * fs);
+        const uint2 send = hi ? lo : up;
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 32, 64); recv.y = __shfl_xor(send.y, 32, 64);
+        const uint4 out = hi ? make_uint4(recv.x, recv.y, up.x, up.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
+        if (qi < p.P) stg16(op + blk * 32 + 16 * m, out);
+      }
+    return;
+  }
+  if (qi >= p.P) return;
+  lvd_bf16* op = p.dq + ((long)f * p.P + qi) * p.lddq + h * 64 + 4 * hi;
+  float* ap = p.acc32 + ((long)f * p.P + qi) * p.ldacc + h * 64 + 4 * hi;  // token chunks are summed in fp32 (acc_mode, lvdhip.h)
+  const float fs = p.scale;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    f32x4 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v0[e] = dq0[rq * 4 + e] * fs; v1[e] = dq1[rq * 4 + e] * fs; }
+    if (p.acc_mode >= 2) {
+      v0 += *reinterpret_cast<const f32x4*>(ap + 8 * rq);
+      v1 += *reinterpret_cast<const f32x4*>(ap + 32 + 8 * rq);
+    }
+    if (p.acc_mode == 1 || p.acc_mode == 2) {
+      *reinterpret_cast<f32x4*>(ap + 8 * rq) = v0;
+      *reinterpret_cast<f32x4*>(ap + 32 + 8 * rq) = v1;
+    } else {
+      uint2 w0, w1;
+      w0.x = pack2bf(v0[0], v0[1]); w0.y = pack2bf(v0[2], v0[3]);
+      w1.x = pack2bf(v1[0], v1[1]); w1.y = pack2bf(v1[2], v1[3]);
+      stg8(op + 8 * rq, w0);
+      stg8(op + 32 + 8 * rq, w1);
+    }
+  }
+}
+
 // NT = compile-time bound on the object tokens of the launch (2 / 4 / 8 / 16): the per-score test "is this key one of the object tokens"
 // costs 16 x NT selects per key tile, and with the bound fixed at 16 it was the kernel (768 VALU operations per tile against 8 MFMAs).
 template <int NT>
@@ -434,69 +596,161 @@ LVD_DEV void ca_dq_body(const lvd_ca_dq_params& p, const int bx, const int by) {
     }
     __syncthreads();
   }
-  if (qi < p.P) {
-    lvd_bf16* op = p.dq + ((long)f * p.P + qi) * p.lddq + h * 64 + 4 * hi;
-    float* ap = p.acc32 + ((long)f * p.P + qi) * p.ldacc + h * 64 + 4 * hi;  // token chunks are summed in fp32 (acc_mode, lvdhip.h)
-    const float fs = p.scale;
+  ca_dq_store(p, f, qi, h, hi, dq0, dq1);
+}
+
+// Short prompts (<= 96 text positions): four query tiles of one head per workgroup.  K^T of the head (all three key tiles) is staged once
+// for the four waves — wave w stages key tile w — behind a single barrier, and every global load of a wave (query rows, LSE, the token
+// columns, the twelve key fragments of S = K.Q^T) is in flight before that barrier; the one-wave body above pays two barriers, a staging
+// pass and a dependent load per key tile and wave.  bx counts (frame, query tile) pairs; the last workgroup of a head may hold idle waves.
+template <int NT>
+LVD_DEV void ca_dq_body4(const lvd_ca_dq_params& p, const int bx, const int by) {
+  __shared__ uint32_t kt_lds[3][64 * TP];
+  __shared__ uint32_t k_lds[96 * KROW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.P + 31) >> 5;
+  const bool live = bx < nqt * p.frames;
+  const int bxc = live ? bx : nqt * p.frames - 1;
+  const int f = bxc / nqt, qt = bxc - f * nqt, h = by;
+  const int qi = qt * 32 + l31;
+  const int qic = min(qi, p.P - 1);
+  const lvd_bf16* qp = p.q + ((long)f * p.P + qic) * p.ldq + h * 64 + hi * 8;
+  bf16x8 qf[4];
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 v0, v1;
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
+  const long row = ((long)f * p.heads + h);
+  const float lse2 = p.lse[row * p.P + qic] * 1.4426950408889634f;
+  const float sc = p.scale * 1.4426950408889634f;
+  float da[NT], pa[NT];
+  int tk[NT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = dq0[rq * 4 + e] * fs; v1[e] = dq1[rq * 4 + e] * fs; }
-      if (p.acc_mode >= 2) {
-        v0 += *reinterpret_cast<const f32x4*>(ap + 8 * rq);
-        v1 += *reinterpret_cast<const f32x4*>(ap + 32 + 8 * rq);
-      }
-      if (p.acc_mode == 1 || p.acc_mode == 2) {
-        *reinterpret_cast<f32x4*>(ap + 8 * rq) = v0;
-        *reinterpret_cast<f32x4*>(ap + 32 + 8 * rq) = v1;
-      } else {
-        uint2 w0, w1;
-        w0.x = pack2bf(v0[0], v0[1]); w0.y = pack2bf(v0[2], v0[3]);
-        w1.x = pack2bf(v1[0], v1[1]); w1.y = pack2bf(v1[2], v1[3]);
-        stg8(op + 8 * rq, w0);
-        stg8(op + 32 + 8 * rq, w1);
-      }
+  for (int t = 0; t < NT; ++t) {
+    const int tt = min(t, p.ntok - 1);
+    const long idx = (row * p.ntok + tt) * p.P + qic;
+    da[t] = p.dprobs[idx];
+    pa[t] = p.probs[idx];
+    tk[t] = p.tok_ids[tt];
+  }
+  const KStage krows = kstage_load(p.k, p.ldk, p.ntext, h);
+  if (wave < 3) {
+    const int vj = lane & 15, vdc = lane >> 4;
+    const int k0 = min(wave * 32 + 2 * vj, p.ntext - 1), k1 = min(wave * 32 + 2 * vj + 1, p.ntext - 1);
+    stage_transposed(kt_lds[wave], p.k + (long)k0 * p.ldk + h * 64, p.k + (long)k1 * p.ldk + h * 64, vj, vdc);
+  }
+  kstage_store(k_lds, krows);
+  __syncthreads();
+  if (!live) return;
+  float cq = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t >= p.ntok) { da[t] = 0.f; tk[t] = -1; }
+    cq += pa[t] * da[t];
+  }
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq0[e] = 0.f; dq1[e] = 0.f; }
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kstage_frag(k_lds, kt, ks, l31, hi), qf[ks], st, 0, 0, 0);
+    // d(score) = prob * (d(prob) - c): d(prob) is non-zero at the object tokens' text positions only.  A token's position is wave-uniform,
+    // so only the tile that holds it tests its 16 accumulator slots (the kernel is VALU-bound: a test of every slot against every token
+    // was 2/3 of its instructions)
+    float g[16], ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[e] = -cq;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if ((tk[t] >> 5) != kt) continue;  // also skips the unused slots (tk = -1)
+      const int r = (tk[t] & 31) - 4 * hi;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) g[e] += ((e & 3) + 8 * (e >> 2) == r) ? da[t] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      ds[e] = kidx < p.ntext ? fast_exp2(st[e] * sc - lse2) * g[e] : 0.f;
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      uint4 w;
+      w.x = pack2bf(ds[ks2 * 8 + 0], ds[ks2 * 8 + 1]); w.y = pack2bf(ds[ks2 * 8 + 2], ds[ks2 * 8 + 3]);
+      w.z = pack2bf(ds[ks2 * 8 + 4], ds[ks2 * 8 + 5]); w.w = pack2bf(ds[ks2 * 8 + 6], ds[ks2 * 8 + 7]);
+      const bf16x8 dsf = as_bf16x8(w);
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(kt_lds[kt], l31, ks2, hi), dsf, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(kt_lds[kt], 32 + l31, ks2, hi), dsf, dq1, 0, 0, 0);
     }
   }
+  ca_dq_store(p, f, qi, h, hi, dq0, dq1);
 }
 
 // ------------------------------------------------------------------------------------ kernels: one key, or all keys of an iteration
 // The six guidance keys of an iteration are independent and small (180-720 query positions x 10-20 heads): launched one by one they are
-// 18 launches of latency-bound one-wave workgroups.  The *_multi kernels take the per-key parameter blocks as ONE kernel argument and
-// blockIdx.z picks the key; a block outside its key's own grid leaves at once (the grid is the largest key's).
+// 18 launches of latency-bound one-wave workgroups.  The multi-key kernels take the per-key parameter blocks as ONE kernel argument and a
+// FLAT grid: start[i] is the first workgroup of key i, so no workgroup is launched only to find itself outside its key (with a
+// (largest key) x keys grid two thirds of the probs / dq workgroups were such no-ops).
 template <class P>
 struct KeyTable {
   P k[LVD_CA_MAX_KEYS];
+  int start[LVD_CA_MAX_KEYS + 1];
+  int nkeys;
 };
-LVD_DEV int probs_gx(const lvd_ca_probs_params& p) { return ((p.P + 31) >> 5) * p.frames; }
-LVD_DEV int dq_gx(const lvd_ca_dq_params& p) { return ((p.P + 31) >> 5) * p.frames; }
+template <class P>
+LVD_DEV int key_of_block(const KeyTable<P>& tab, int b) {
+  int key = 0;
+#pragma unroll
+  for (int i = 1; i < LVD_CA_MAX_KEYS; ++i) key += (i < tab.nkeys && b >= tab.start[i]) ? 1 : 0;
+  return key;
+}
+template <class P>
+LVD_DEV int tiles_of(const P& p) { return ((p.P + 31) >> 5) * p.frames; }  // (frame, 32-query tile) pairs of a key
 
-__global__ __launch_bounds__(64) void ca_probs_kernel(const lvd_ca_probs_params p) { ca_probs_body(p, blockIdx.x, blockIdx.y); }
+// long prompts (> 96 text positions): the general one-wave bodies, workgroup = (tile, head)
 __global__ __launch_bounds__(64) void ca_probs_multi_kernel(const KeyTable<lvd_ca_probs_params> tab) {
-  const lvd_ca_probs_params& p = tab.k[blockIdx.z];
-  if ((int)blockIdx.x >= probs_gx(p) || (int)blockIdx.y >= p.heads) return;
-  ca_probs_body(p, blockIdx.x, blockIdx.y);
+  const int key = key_of_block(tab, blockIdx.x);
+  const lvd_ca_probs_params& p = tab.k[key];
+  const int u = blockIdx.x - tab.start[key], tiles = tiles_of(p);
+  ca_probs_body(p, u % tiles, u / tiles);
 }
-__global__ void ca_com_kernel(const lvd_ca_select_params p) { ca_com_body(p, blockIdx.x); }
+// Four query tiles of one head per workgroup; the head runs fastest over consecutive workgroups, so the 128-byte head slices of the same
+// query rows are fetched at about the same time (whole rows, open DRAM pages): 168 -> 154 us for the three stages of the bench layout
+// against tile-fastest order, once the key fragments came from LDS (before that the order made no difference: the loads were the limit).
+__global__ __launch_bounds__(256) void ca_probs3_multi_kernel(const KeyTable<lvd_ca_probs_params> tab) {
+  const int key = key_of_block(tab, blockIdx.x);
+  const lvd_ca_probs_params& p = tab.k[key];
+  const int u = blockIdx.x - tab.start[key];
+  ca_probs_body3(p, (u / p.heads) * 4 + (threadIdx.x >> 6), u % p.heads);
+}
 __global__ void ca_com_multi_kernel(const KeyTable<lvd_ca_select_params> tab) {
-  const lvd_ca_select_params& p = tab.k[blockIdx.y];
-  if ((int)blockIdx.x >= p.frames * p.heads * p.ntok) return;
-  ca_com_body(p, blockIdx.x);
+  const int key = key_of_block(tab, blockIdx.x);
+  ca_com_body(tab.k[key], blockIdx.x - tab.start[key]);
 }
-__global__ __launch_bounds__(256) void ca_select_kernel(const lvd_ca_select_params p) { ca_select_body(p, blockIdx.x); }
-__global__ __launch_bounds__(256) void ca_select_multi_kernel(const KeyTable<lvd_ca_select_params> tab) {
-  const lvd_ca_select_params& p = tab.k[blockIdx.y];
-  if ((int)blockIdx.x >= p.frames * p.heads * p.ntok) return;
-  ca_select_body(p, blockIdx.x);
+template <int E>
+__global__ __launch_bounds__(256) void ca_select_multi_kernel(const KeyTable<lvd_ca_select_params> tab, const int ws_words) {
+  extern __shared__ unsigned int select_ws[];
+  const int wave = threadIdx.x >> 6;
+  const int key = key_of_block(tab, blockIdx.x);
+  const lvd_ca_select_params& p = tab.k[key];
+  const int b = (blockIdx.x - tab.start[key]) * 4 + wave;
+  if (b >= p.frames * p.heads * p.ntok) return;  // the waves of a workgroup never meet at a barrier
+  ca_select_wave<E>(p, b, select_ws + wave * ws_words);
 }
-template <int NT>
-__global__ __launch_bounds__(64) void ca_dq_kernel(const lvd_ca_dq_params p) { ca_dq_body<NT>(p, blockIdx.x, blockIdx.y); }
 template <int NT>
 __global__ __launch_bounds__(64) void ca_dq_multi_kernel(const KeyTable<lvd_ca_dq_params> tab) {
-  const lvd_ca_dq_params& p = tab.k[blockIdx.z];
-  if ((int)blockIdx.x >= dq_gx(p) || (int)blockIdx.y >= p.heads) return;
-  ca_dq_body<NT>(p, blockIdx.x, blockIdx.y);
+  const int key = key_of_block(tab, blockIdx.x);
+  const lvd_ca_dq_params& p = tab.k[key];
+  const int u = blockIdx.x - tab.start[key], tiles = tiles_of(p);
+  ca_dq_body<NT>(p, u % tiles, u / tiles);
+}
+template <int NT>
+__global__ __launch_bounds__(256) void ca_dq4_multi_kernel(const KeyTable<lvd_ca_dq_params> tab) {
+  const int key = key_of_block(tab, blockIdx.x);
+  const lvd_ca_dq_params& p = tab.k[key];
+  const int u = blockIdx.x - tab.start[key];
+  ca_dq_body4<NT>(p, (u / p.heads) * 4 + (threadIdx.x >> 6), u % p.heads);  // head fastest, as in ca_probs3_multi_kernel
 }
 
 }  // namespace
@@ -522,96 +776,105 @@ int check_dq(const lvd_ca_dq_params* p) {
 }  // namespace
 
 // All keys of a guidance iteration in one launch each (3 launches instead of 3 per key; 4 with the centre-of-mass term).  `keys` is a
-// host array of `nkeys` (<= LVD_CA_MAX_KEYS) parameter blocks, each exactly what the single-key entry point takes.
+// host array of `nkeys` (<= LVD_CA_MAX_KEYS) parameter blocks, each exactly what the single-key entry point takes; the single-key entry
+// points are the nkeys = 1 case of the same kernels.
+namespace {
+template <class P, class F>
+int fill_table(KeyTable<P>& tab, const P* keys, int nkeys, F blocks_of) {
+  tab.nkeys = nkeys;
+  int total = 0;
+  for (int i = 0; i < LVD_CA_MAX_KEYS; ++i) {
+    tab.start[i] = total;
+    if (i < nkeys) {
+      tab.k[i] = keys[i];
+      total += blocks_of(keys[i]);
+    }
+  }
+  tab.start[LVD_CA_MAX_KEYS] = total;
+  return total;
+}
+template <class P>
+int host_tiles(const P& p) { return ((p.P + 31) / 32) * p.frames; }
+}  // namespace
+
 extern "C" int lvdhip_ca_probs_multi(const lvd_ca_probs_params* keys, int32_t nkeys, void* stream) {
   LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_probs_multi: 1..%d keys", LVD_CA_MAX_KEYS);
-  KeyTable<lvd_ca_probs_params> tab;
-  int gx = 0, gy = 0;
+  bool brief = true;
   for (int i = 0; i < nkeys; ++i) {
     if (int rc = check_probs(keys + i)) return rc;
-    tab.k[i] = keys[i];
-    gx = std::max(gx, ((keys[i].P + 31) / 32) * keys[i].frames);
-    gy = std::max(gy, keys[i].heads);
+    brief = brief && keys[i].ntext <= 96;
   }
-  hipLaunchKernelGGL(ca_probs_multi_kernel, dim3(gx, gy, nkeys), dim3(64), 0, (hipStream_t)stream, tab);
+  KeyTable<lvd_ca_probs_params> tab;
+  if (brief) {
+    const int blocks = fill_table(tab, keys, nkeys, [](const lvd_ca_probs_params& p) { return ((host_tiles(p) + 3) / 4) * p.heads; });
+    hipLaunchKernelGGL(ca_probs3_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab);
+  } else {
+    const int blocks = fill_table(tab, keys, nkeys, [](const lvd_ca_probs_params& p) { return host_tiles(p) * p.heads; });
+    hipLaunchKernelGGL(ca_probs_multi_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, tab);
+  }
   LVD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t nkeys, void* stream) {
   LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_select_multi: 1..%d keys", LVD_CA_MAX_KEYS);
-  KeyTable<lvd_ca_select_params> tab;
-  int blocks = 0;
-  size_t smem = 0;
+  int pmax = 0;
   bool com = false;
   for (int i = 0; i < nkeys; ++i) {
     if (int rc = check_select(keys + i)) return rc;
-    tab.k[i] = keys[i];
-    blocks = std::max(blocks, keys[i].frames * keys[i].heads * keys[i].ntok);
-    smem = std::max(smem, (size_t)keys[i].P * 5 + 16);
+    pmax = std::max(pmax, keys[i].P);
     com = com || keys[i].com_loss_scale > 0.f;
     LVD_CHECK((keys[i].com_loss_scale > 0.f) == (keys[0].com_loss_scale > 0.f), "ca_select_multi: the centre-of-mass term is on for all keys or for none");
   }
   hipStream_t s = (hipStream_t)stream;
   if (com) {
-    hipLaunchKernelGGL(ca_com_multi_kernel, dim3(blocks, nkeys), dim3(256), 0, s, tab);
+    KeyTable<lvd_ca_select_params> tab;
+    const int blocks = fill_table(tab, keys, nkeys, [](const lvd_ca_select_params& p) { return p.frames * p.heads * p.ntok; });
+    hipLaunchKernelGGL(ca_com_multi_kernel, dim3(blocks), dim3(256), 0, s, tab);
     LVD_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(ca_select_multi_kernel, dim3(blocks, nkeys), dim3(256), smem, s, tab);
+  KeyTable<lvd_ca_select_params> tab;
+  const int blocks = fill_table(tab, keys, nkeys, [](const lvd_ca_select_params& p) { return (p.frames * p.heads * p.ntok + 3) / 4; });
+  const int ws_words = 512 + ((pmax + 3) & ~3);  // per wave: two histograms, then the map (BoxDiff)
+  const size_t smem = (size_t)4 * ws_words * sizeof(unsigned int);
+  const int e = (pmax + 63) / 64;  // map entries per lane
+  if (e <= 3) hipLaunchKernelGGL(ca_select_multi_kernel<3>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
+  else if (e <= 12) hipLaunchKernelGGL(ca_select_multi_kernel<12>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
+  else if (e <= 24) hipLaunchKernelGGL(ca_select_multi_kernel<24>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
+  else hipLaunchKernelGGL(ca_select_multi_kernel<64>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
   LVD_LAUNCH_CHECK();
   return 0;
 }
+
+namespace {
+template <int NT>
+void launch_dq(const KeyTable<lvd_ca_dq_params>& tab, int blocks, bool brief, hipStream_t s) {
+  if (brief) hipLaunchKernelGGL(ca_dq4_multi_kernel<NT>, dim3(blocks), dim3(256), 0, s, tab);
+  else hipLaunchKernelGGL(ca_dq_multi_kernel<NT>, dim3(blocks), dim3(64), 0, s, tab);
+}
+}  // namespace
 
 extern "C" int lvdhip_ca_dq_multi(const lvd_ca_dq_params* keys, int32_t nkeys, void* stream) {
   LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_dq_multi: 1..%d keys", LVD_CA_MAX_KEYS);
-  KeyTable<lvd_ca_dq_params> tab;
-  int gx = 0, gy = 0, nt = 0;
+  int nt = 0;
+  bool brief = true;
   for (int i = 0; i < nkeys; ++i) {
     if (int rc = check_dq(keys + i)) return rc;
-    tab.k[i] = keys[i];
-    gx = std::max(gx, ((keys[i].P + 31) / 32) * keys[i].frames);
-    gy = std::max(gy, keys[i].heads);
     nt = std::max(nt, keys[i].ntok);
+    brief = brief && keys[i].ntext <= 96;
   }
-  const dim3 grid(gx, gy, nkeys);
+  KeyTable<lvd_ca_dq_params> tab;
+  const int blocks = brief ? fill_table(tab, keys, nkeys, [](const lvd_ca_dq_params& p) { return ((host_tiles(p) + 3) / 4) * p.heads; })
+                           : fill_table(tab, keys, nkeys, [](const lvd_ca_dq_params& p) { return host_tiles(p) * p.heads; });
   hipStream_t s = (hipStream_t)stream;
-  if (nt <= 2) hipLaunchKernelGGL(ca_dq_multi_kernel<2>, grid, dim3(64), 0, s, tab);
-  else if (nt <= 4) hipLaunchKernelGGL(ca_dq_multi_kernel<4>, grid, dim3(64), 0, s, tab);
-  else if (nt <= 8) hipLaunchKernelGGL(ca_dq_multi_kernel<8>, grid, dim3(64), 0, s, tab);
-  else hipLaunchKernelGGL(ca_dq_multi_kernel<MAXTOK>, grid, dim3(64), 0, s, tab);
+  if (nt <= 2) launch_dq<2>(tab, blocks, brief, s);
+  else if (nt <= 4) launch_dq<4>(tab, blocks, brief, s);
+  else if (nt <= 8) launch_dq<8>(tab, blocks, brief, s);
+  else launch_dq<MAXTOK>(tab, blocks, brief, s);
   LVD_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) {
-  if (int rc = check_probs(p)) return rc;
-  dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
-  hipLaunchKernelGGL(ca_probs_kernel, grid, dim3(64), 0, (hipStream_t)stream, *p);
-  LVD_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) {
-  if (int rc = check_select(p)) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  int blocks = p->frames * p->heads * p->ntok;
-  if (p->com_loss_scale > 0.f) {
-    hipLaunchKernelGGL(ca_com_kernel, dim3(blocks), dim3(256), 0, s, *p);
-    LVD_LAUNCH_CHECK();
-  }
-  size_t smem = (size_t)p->P * 5 + 16;
-  hipLaunchKernelGGL(ca_select_kernel, dim3(blocks), dim3(256), smem, s, *p);
-  LVD_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) {
-  if (int rc = check_dq(p)) return rc;
-  dim3 grid(((p->P + 31) / 32) * p->frames, p->heads);
-  if (p->ntok <= 2) hipLaunchKernelGGL(ca_dq_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, *p);
-  else if (p->ntok <= 4) hipLaunchKernelGGL(ca_dq_kernel<4>, grid, dim3(64), 0, (hipStream_t)stream, *p);
-  else if (p->ntok <= 8) hipLaunchKernelGGL(ca_dq_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, *p);
-  else hipLaunchKernelGGL(ca_dq_kernel<MAXTOK>, grid, dim3(64), 0, (hipStream_t)stream, *p);
-  LVD_LAUNCH_CHECK();
-  return 0;
-}
+extern "C" int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream) { return lvdhip_ca_probs_multi(p, 1, stream); }
+extern "C" int lvdhip_ca_select(const lvd_ca_select_params* p, void* stream) { return lvdhip_ca_select_multi(p, 1, stream); }
+extern "C" int lvdhip_ca_dq(const lvd_ca_dq_params* p, void* stream) { return lvdhip_ca_dq_multi(p, 1, stream); }

@@ -105,6 +105,34 @@ def test_fused_loss_kernels_vs_oracle(com):
     assert rel(dq, gq) < 1.5e-2, rel(dq, gq)   # dq is stored in bf16
 
 
+@pytest.mark.parametrize("Hh,Ww,nt", [(8, 12, 130), (20, 36, 77), (24, 40, 40), (40, 72, 77)])
+def test_fused_loss_map_sizes_and_prompt_lengths(Hh, Ww, nt):
+    """The kernels' other instantiations: prompts past 96 text positions (general one-wave probs / dQ bodies instead of the three-tile
+    ones) and maps of 720 / 960 / 2880 positions (12 / 24 / 64 map entries per lane in the wave-per-map select), BoxDiff on (it reads
+    the map back by position) — same oracle, same bounds as the 8x12 case."""
+    frames, heads = 2, 2
+    P, C = Hh * Ww, heads * 64
+    q = rnd(frames * P, C, seed=11, scale=1.5).bfloat16()
+    k = rnd(nt, C, seed=12).bfloat16()
+    bboxes = [[[0.1, 0.2, 0.55, 0.8], [0.15, 0.2, 0.6, 0.8]], [[0.5, 0.5, 0.9, 0.95], [0.4, 0.45, 0.8, 0.9]]]
+    pos = [[2, 3], [6]]
+    from test_oracle import LOSS_VARIANTS
+    hp = dict(fg_top_p=0.3, bg_top_p=0.4, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03)
+    hp.update(LOSS_VARIANTS["boxdiff"])
+    qa = q.float().requires_grad_(True)
+    probs = (qa.reshape(frames, P, heads, 64).permute(0, 2, 1, 3) @ k.float().reshape(nt, heads, 64).permute(1, 2, 0)[None] * 0.125).softmax(-1)
+    ref = guidance_ref.compute_ca_loss({"k": probs}, bboxes, pos, ["k"], (Hh, Ww), **hp) * 5.0
+    (gq,) = torch.autograd.grad(ref, qa)
+    lay = guidance.GuidanceLayout(bboxes, pos, frames, Hh, Ww, hp["fg_top_p"], hp["bg_top_p"], DEV)
+    partial = torch.zeros(frames * heads * 3, device=DEV)
+    gs = 5.0 / len(bboxes)
+    hip_kw = {kk: v for kk, v in hp.items() if kk not in ("fg_top_p", "bg_top_p")}
+    dq = guidance.ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=nt, grad_scale=gs, loss_partial=partial, **hip_kw)
+    loss = ops.reduce_sum(partial, gs).item()
+    assert abs(loss - ref.item()) < 3e-4 * abs(ref.item()), (loss, ref.item())
+    assert rel(dq, gq) < 1.5e-2, rel(dq, gq)
+
+
 @pytest.mark.parametrize("case", ["ratio", "sync", "boxdiff", "boxdiff_sum", "all"])
 def test_fused_loss_optional_terms_vs_oracle_and_reference(case):
     """Ratio-based energy, attention sync, BoxDiff corner constraint in the fused kernel: (i) on projected Q/K vs autograd through

@@ -2,6 +2,7 @@
 3-object / 4-token layout: time per key and per iteration, HBM GB/s against the floor (read Q + write dQ of the keyed layers: 177 MB)."""
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -51,10 +52,14 @@ for name, fn, launches in (("key by key", key_by_key, 18), ("all keys per launch
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
+    t0 = time.perf_counter()
     for _ in range(20):
         fn()
+    host = (time.perf_counter() - t0) / 20 * 1e6
     e.record()
     e.synchronize()
     us = s.elapsed_time(e) / 20 * 1e3
-    print(f"guidance loss, 6 keys, {ntok} object tokens, {name} ({launches} launches): {us:.0f} us per iteration; "
-          f"algorithmic traffic {mb:.0f} MB (read Q + write dQ) -> {mb / us:.3f} TB/s = {mb / us / 8.0:.3f} of the 8 TB/s HBM figure")
+    print(f"guidance loss, 6 keys, {ntok} object tokens, {name} ({launches} launches): {us:.0f} us per iteration on the device timeline "
+          f"(host issue {host:.0f} us per iteration: back-to-back iterations are host-bound when that is the larger figure; the step issues "
+          f"the loss behind a long forward); algorithmic traffic {mb:.0f} MB (read Q + write dQ) -> {mb / us:.3f} TB/s = {mb / us / 8.0:.3f} "
+          f"of the 8 TB/s HBM figure")
