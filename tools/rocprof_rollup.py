@@ -12,7 +12,7 @@ CLASSES = [
     ("GroupNorm", ("gn_",)),
     ("attention fwd/bwd", ("attn_",)),
     ("LayerNorm", ("ln_",)),
-    ("guidance loss (3 kernels/key)", ("ca_",)),
+    ("guidance loss (3 launches for all keys of an iteration)", ("ca_",)),
     ("elementwise / layout (incl. the temporal-conv combine pass)", ("geglu_", "add_kernel", "silu_kernel", "tokens", "upsample2x", "timestep_embedding", "cfg_dpm", "axpy", "reduce_sum", "tconv_combine")),
 ]
 
