@@ -819,10 +819,11 @@ extern "C" int lvdhip_ca_probs_multi(const lvd_ca_probs_params* keys, int32_t nk
 extern "C" int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t nkeys, void* stream) {
   LVD_CHECK(keys && nkeys >= 1 && nkeys <= LVD_CA_MAX_KEYS, "ca_select_multi: 1..%d keys", LVD_CA_MAX_KEYS);
   int pmax = 0;
-  bool com = false;
+  bool com = false, boxdiff = false;
   for (int i = 0; i < nkeys; ++i) {
     if (int rc = check_select(keys + i)) return rc;
     pmax = std::max(pmax, keys[i].P);
+    boxdiff = boxdiff || keys[i].boxdiff_loss_scale > 0.f;
     com = com || keys[i].com_loss_scale > 0.f;
     LVD_CHECK((keys[i].com_loss_scale > 0.f) == (keys[0].com_loss_scale > 0.f), "ca_select_multi: the centre-of-mass term is on for all keys or for none");
   }
@@ -835,13 +836,22 @@ extern "C" int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t 
   }
   KeyTable<lvd_ca_select_params> tab;
   const int blocks = fill_table(tab, keys, nkeys, [](const lvd_ca_select_params& p) { return (p.frames * p.heads * p.ntok + 3) / 4; });
-  const int ws_words = 512 + ((pmax + 3) & ~3);  // per wave: two histograms, then the map (BoxDiff)
+  // per wave: two histograms, then (only when a key has the BoxDiff term, which reads the map back by position) the map itself
+  const int ws_words = 512 + (boxdiff ? ((pmax + 3) & ~3) : 0);
   const size_t smem = (size_t)4 * ws_words * sizeof(unsigned int);
   const int e = (pmax + 63) / 64;  // map entries per lane
-  if (e <= 3) hipLaunchKernelGGL(ca_select_multi_kernel<3>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
-  else if (e <= 12) hipLaunchKernelGGL(ca_select_multi_kernel<12>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
-  else if (e <= 24) hipLaunchKernelGGL(ca_select_multi_kernel<24>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
-  else hipLaunchKernelGGL(ca_select_multi_kernel<64>, dim3(blocks), dim3(256), smem, s, tab, ws_words);
+  auto launch = [&](auto kernel) {
+    if (smem > 48 * 1024)  // 4 maps of up to 4096 positions: past the default dynamic-LDS limit, well inside the CU's 160 KB
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), smem, s, tab, ws_words);
+    return 0;
+  };
+  int rc;
+  if (e <= 3) rc = launch(ca_select_multi_kernel<3>);
+  else if (e <= 12) rc = launch(ca_select_multi_kernel<12>);
+  else if (e <= 24) rc = launch(ca_select_multi_kernel<24>);
+  else rc = launch(ca_select_multi_kernel<64>);
+  LVD_CHECK(rc == 0, "ca_select_multi: %zu bytes of LDS per workgroup refused", smem);
   LVD_LAUNCH_CHECK();
   return 0;
 }
