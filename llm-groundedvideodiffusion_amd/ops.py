@@ -239,6 +239,15 @@ def _gn_chunks(samples, rows_per_sample, min_rows=64):
     return max(1, min(want, rows_per_sample // min_rows if rows_per_sample >= min_rows else 1))
 
 
+def _gn_min_rows(c):
+    """Rows per statistics chunk, at least: a workgroup has 512 // (c / 8) row lanes (norm.hip gn_geometry) and a lane walks its rows eight at
+    a time.  64 rows is three trips at c <= 1280; the wide two-source norms of the up blocks (c = 1920 / 2560: two row lanes / one) would walk
+    32 / 64 rows per lane — the level-2 norm over [x, skip] (c = 2560, 180 rows per sample) spent 26 us in two chunks per sample
+    (profiles/r04_gn_cooperative_experiment.txt)."""
+    row_lanes = max(1, 512 // max(1, c // 8))
+    return min(64, 24 * row_lanes)
+
+
 @dataclass
 class GnStats:
     """Statistics partials of a GroupNorm ([samples, chunks, groups, 2] sums) plus what the apply launch needs to finish them."""
@@ -258,7 +267,7 @@ def groupnorm_stats(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, x2
     c1 = x1.shape[1]
     c = c1 + (x2.shape[1] if x2 is not None else 0)
     samples = rows // rows_per_sample
-    chunks = _gn_chunks(samples, rows_per_sample)
+    chunks = _gn_chunks(samples, rows_per_sample, _gn_min_rows(c))
     dev = x1.device
     partial = torch.empty((samples, chunks, groups, 2), dtype=torch.float32, device=dev)
     p = hip.GnStatsParams()

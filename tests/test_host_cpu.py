@@ -290,6 +290,8 @@ def test_groupnorm_chunking_rules():
     assert ops._gn_chunks(2, 1080) == 16             # 5x9 level, forward: 64-row chunks
     assert ops._gn_chunks(2, 1080, 32) == 33         # ... backward statistics: 32-row chunks
     assert ops._gn_chunks(4096, 10) == 1 and ops._gn_chunks(1, 1) == 1
+    assert [ops._gn_min_rows(c) for c in (320, 640, 1280, 1920, 2560)] == [64, 64, 64, 48, 24]
+    assert ops._gn_chunks(24, 180, ops._gn_min_rows(2560)) == 7   # level 2, norm over [x, skip]: one row lane per workgroup, 24-row chunks (was 2 chunks)
 
 
 def test_test_tokenizer_ids_do_not_depend_on_call_order():
