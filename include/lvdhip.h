@@ -196,6 +196,19 @@ int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void* stream);
  * backward.  Needs an even number of channels per group. */
 int lvdhip_groupnorm_fused(const lvd_gn_stats_params* s, const lvd_gn_apply_params* a, void* stream);
 int lvdhip_groupnorm_bwd_fused(const lvd_gn_bwd_apply_params* p, void* stream);
+/* Single launch for the slabs in between (30-200 KB per (sample, group): the 2-D norms of the 40x72 / 20x36 levels, the 5-D norms of the
+ * temporal layers on the 5x9 level, the norm over [x, skip] at 2560 channels): a 1024-thread workgroup loads its whole slab at once,
+ * keeps it in registers — x is read once —, reduces and normalises.  A thread's load is the widest of 16 / 8 / 4 bytes (8 / 4 / 2
+ * channels) that divides the channels per group.  Arguments as for lvdhip_groupnorm_fused (row pitches multiples of 8 elements).
+ * lvdhip_groupnorm_slab_loads returns the loads per thread (>= 1) or 0 when the shape does not qualify: an even number of channels per
+ * group, a group inside one source (c1 % (c/groups) == 0), and rows_per_sample <= U * (1024 / (c / groups / V)) with
+ * (V channels per load, U loads) = (8, 12), (4, 8) or (2, 8). */
+int lvdhip_groupnorm_slab_loads(int32_t c, int32_t c1, int32_t groups, int32_t rows_per_sample);
+int lvdhip_groupnorm_slab(const lvd_gn_stats_params* s, const lvd_gn_apply_params* a, void* stream);
+/* ... and its backward: x and dy of the slab in registers (at most 64 bytes of each per thread: lvdhip_groupnorm_bwd_slab_loads returns the
+ * pairs of loads per thread, or 0).  Arguments as for lvdhip_groupnorm_bwd_fused. */
+int lvdhip_groupnorm_bwd_slab_loads(int32_t c, int32_t c1, int32_t groups, int32_t rows_per_sample);
+int lvdhip_groupnorm_bwd_slab(const lvd_gn_bwd_apply_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over channels (BasicTransformerBlock.norm1/2/3, GatedSelfAttentionDense.norm1/2

@@ -150,6 +150,10 @@ SYMBOLS = {
     "lvdhip_groupnorm_bwd_apply": [_P(GnBwdApplyParams), C.c_void_p],
     "lvdhip_groupnorm_fused": [_P(GnStatsParams), _P(GnApplyParams), C.c_void_p],
     "lvdhip_groupnorm_bwd_fused": [_P(GnBwdApplyParams), C.c_void_p],
+    "lvdhip_groupnorm_slab_loads": [C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+    "lvdhip_groupnorm_slab": [_P(GnStatsParams), _P(GnApplyParams), C.c_void_p],
+    "lvdhip_groupnorm_bwd_slab_loads": [C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+    "lvdhip_groupnorm_bwd_slab": [_P(GnBwdApplyParams), C.c_void_p],
     "lvdhip_layernorm": [_P(LnParams), C.c_void_p],
     "lvdhip_layernorm_bwd": [_P(LnBwdParams), C.c_void_p],
     "lvdhip_attention_fwd": [_P(AttnParams), C.c_void_p],
@@ -186,7 +190,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 102
+ABI_VERSION = 103
 CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 

@@ -298,7 +298,8 @@ def groupnorm_apply(x1, stats: GnStats, rows_per_sample, *, silu=False, x2=None,
 # Small samples take the single-launch kernels (norm_small.hip): a (sample, group) slab of at most 64 Ki elements (128 KB: its
 # second pass is an L2 hit) and a tensor small enough that the three launches of the two-stage path are launch-bound.
 _gn_fused = {"max_slab": 65536, "max_bytes": int(os.environ.get("LVD_GN_FUSED_MAX_MB", "24")) << 20,
-             "max_rows_per_thread": int(os.environ.get("LVD_GN_FUSED_MAX_ROWS", "16"))}
+             "max_rows_per_thread": int(os.environ.get("LVD_GN_FUSED_MAX_ROWS", "16")),
+             "max_bytes_slab": int(os.environ.get("LVD_GN_SLAB_MAX_MB", "128")) << 20}  # 0: the slab-in-registers kernel is off
 
 
 def groupnorm_fused_ok(rows, c, rows_per_sample, groups):
@@ -311,8 +312,8 @@ def groupnorm_fused_ok(rows, c, rows_per_sample, groups):
     return -(-rows_per_sample // row_lanes) <= _gn_fused["max_rows_per_thread"]
 
 
-def groupnorm_fused(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None):
-    """GroupNorm(+SiLU) in one launch (small samples).  Returns (y, mean_rstd [S,G,2])."""
+def groupnorm_fused(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None, slab=False):
+    """GroupNorm(+SiLU) in one launch (small samples; slab=True: the slab-in-registers kernel).  Returns (y, mean_rstd [S,G,2])."""
     _chk_bf16(x1, x2)
     _chk_f32(gamma, beta)
     rows, c1 = x1.shape
@@ -326,15 +327,36 @@ def groupnorm_fused(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, si
         q.rows, q.rows_per_sample = rows, rows_per_sample
     s.groups, s.eps, s.gamma, s.beta, s.mean_rstd = groups, eps, _p(gamma), _p(beta), _p(mr)
     a.silu, a.y, a.ldy = int(silu), _p(out), _ld(out)
-    hip.check(hip.lib().lvdhip_groupnorm_fused(C.byref(s), C.byref(a), _stream()), "groupnorm_fused")
+    fn = hip.lib().lvdhip_groupnorm_slab if slab else hip.lib().lvdhip_groupnorm_fused
+    hip.check(fn(C.byref(s), C.byref(a), _stream()), "groupnorm_slab" if slab else "groupnorm_fused")
     return out, mr
 
 
+_slab_loads = {}
+
+
+def groupnorm_slab_ok(rows, c, rows_per_sample, groups, c1=None, backward=False):
+    """The 1024-thread kernels that hold a whole (sample, group) slab in registers (norm_small.hip gn_slab_kernel / gn_bwd_slab_kernel) take
+    this shape: lvdhip_groupnorm_slab_loads / lvdhip_groupnorm_bwd_slab_loads (an even number of channels per group, a group inside one
+    source, few enough loads per thread)."""
+    if rows * c * 2 > _gn_fused["max_bytes_slab"]:
+        return False
+    key = (c, c if c1 is None else c1, groups, rows_per_sample, backward)
+    n = _slab_loads.get(key)
+    if n is None:
+        fn = hip.lib().lvdhip_groupnorm_bwd_slab_loads if backward else hip.lib().lvdhip_groupnorm_slab_loads
+        n = _slab_loads[key] = int(fn(*key[:4]))
+    return n > 0
+
+
 def groupnorm_auto(x1, gamma, beta, rows_per_sample, *, groups=32, eps=1e-5, silu=False, x2=None, out=None):
-    """(y, mean_rstd): the single-launch kernel when the sample is small, the two-stage kernels otherwise."""
+    """(y, mean_rstd): one launch when a (sample, group) slab is small enough for one workgroup — the 256-thread walk for short slabs, the
+    1024-thread slab-in-registers kernel for the ones in between —, the two-stage kernels otherwise."""
     c = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if groupnorm_fused_ok(x1.shape[0], c, rows_per_sample, groups):
         return groupnorm_fused(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, silu=silu, x2=x2, out=out)
+    if groupnorm_slab_ok(x1.shape[0], c, rows_per_sample, groups, x1.shape[1]):
+        return groupnorm_fused(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, silu=silu, x2=x2, out=out, slab=True)
     st = groupnorm_stats(x1, gamma, beta, rows_per_sample, groups=groups, eps=eps, x2=x2)
     return groupnorm_apply(x1, st, rows_per_sample, silu=silu, x2=x2, out=out)
 
@@ -352,7 +374,8 @@ def groupnorm_bwd(x1, dy, gamma, beta, mean_rstd, rows_per_sample, *, groups=32,
     c1 = x1.shape[1]
     c = c1 + (x2.shape[1] if x2 is not None else 0)
     samples = rows // rows_per_sample
-    if groupnorm_fused_ok(rows, c, rows_per_sample, groups):
+    small = groupnorm_fused_ok(rows, c, rows_per_sample, groups)
+    if small or groupnorm_slab_ok(rows, c, rows_per_sample, groups, c1, backward=True):
         if dx1 is None:
             dx1 = torch.empty_like(x1)
             assert not accumulate
@@ -366,7 +389,8 @@ def groupnorm_bwd(x1, dy, gamma, beta, mean_rstd, rows_per_sample, *, groups=32,
         q.dx1, q.dx2 = _p(dx1), _p(dx2)
         q.lddx1, q.lddx2 = _ld(dx1), (_ld(dx2) if dx2 is not None else 0)
         q.accumulate = int(accumulate)
-        hip.check(hip.lib().lvdhip_groupnorm_bwd_fused(C.byref(q), _stream()), "groupnorm_bwd_fused")
+        fn = hip.lib().lvdhip_groupnorm_bwd_fused if small else hip.lib().lvdhip_groupnorm_bwd_slab
+        hip.check(fn(C.byref(q), _stream()), "groupnorm_bwd_fused" if small else "groupnorm_bwd_slab")
         return dx1, dx2
     # the 5-D norms of the deep levels (1-2 samples of 1080 / 4320 rows): 64-row chunks leave the backward statistics pass on 16-67
     # workgroups (34 -> 25 us at 1080 rows, 39 -> 32 us at 4320 with 32-row chunks; larger samples and the forward pass do not gain)

@@ -196,9 +196,9 @@ def test_tconv3():
 # ----------------------------------------------------------------------------- norms
 @pytest.fixture(params=["single_launch", "two_stage"])
 def gn_path(request):
-    """Both GroupNorm implementations on every case: norm_small.hip (one launch per norm) and norm.hip (partial/finalize/apply)."""
+    """Both GroupNorm implementations on every case: norm_small.hip (one launch per norm) and norm.hip (partials, then fold + apply)."""
     saved = dict(ops._gn_fused)
-    ops._gn_fused.update(max_bytes=(1 << 40) if request.param == "single_launch" else 0, max_rows_per_thread=1 << 30)
+    ops._gn_fused.update(max_bytes=(1 << 40) if request.param == "single_launch" else 0, max_rows_per_thread=1 << 30, max_bytes_slab=0)
     yield request.param
     ops._gn_fused.update(saved)
 
@@ -238,6 +238,79 @@ def test_groupnorm(C, rps, samples, two, gn_path):
         ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, silu=True, dx1=buf, accumulate=True)
         close(buf, gref + acc.float(), 1.2e-2, f"groupnorm bwd accumulate C={C}")
     close(got, gref, 1e-2, f"groupnorm bwd C={C}")
+
+
+@pytest.mark.parametrize("C,rps,samples,c1", [(1280, 1080, 1, 0), (1280, 1080, 2, 0), (2560, 180, 24, 1280), (2560, 180, 48, 1280), (2560, 45, 48, 1280),
+                                               (256, 1000, 3, 0), (1280, 2448, 1, 0), (1280, 1231, 9, 0), (512, 777, 5, 256),
+                                               (640, 720, 24, 0), (640, 720, 48, 0), (640, 1500, 4, 320), (1920, 200, 3, 0), (640, 1632, 2, 0),
+                                               (320, 720, 48, 0), (320, 1600, 24, 0), (960, 45, 24, 480), (64, 5000, 2, 0)])
+def test_groupnorm_slab_in_registers(C, rps, samples, c1):
+    """The 1024-thread single-launch kernel (a whole (sample, group) slab in registers) at the step's own shapes — the 5-D norms of the 5x9
+    level, the 2-D norms of the 40x72 / 20x36 levels (4- and 8-byte loads: 10 / 20 channels per group), the norms over [x, skip] — and at odd
+    row counts / every loads-per-thread instantiation / both workgroup numberings (fewer than eight samples, eight or more): against fp32
+    GroupNorm, against the two launches (same statistics up to summation order), (mean, rstd) as the backward expects them."""
+    rows = rps * samples
+    assert ops.groupnorm_slab_ok(rows, C, rps, 32, c1 or C)
+    x = bf(rnd(rows, C, seed=1) * 2 + 0.5)
+    gamma, beta = rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.2
+    xs = (x, None) if not c1 else (x[:, :c1].contiguous(), x[:, c1:].contiguous())
+    ref = F.group_norm(x.float().reshape(samples, rps, C).permute(0, 2, 1), 32, gamma, beta, 1e-5)
+    for silu in (False, True):
+        y, mr = ops.groupnorm_fused(xs[0], gamma, beta, rps, silu=silu, x2=xs[1], slab=True)
+        want = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(rows, C)
+        close(y, want, 6e-3, f"slab groupnorm silu={silu}")
+    st = ops.groupnorm_stats(xs[0], gamma, beta, rps, x2=xs[1])
+    y2, mr2 = ops.groupnorm_apply(xs[0], st, rps, silu=True, x2=xs[1])
+    close(mr, mr2, 1e-5, "slab (mean, rstd) vs two launches")
+    close(y, y2, 4e-3, "slab vs two launches")
+
+
+@pytest.mark.parametrize("C,rps,samples,c1", [(2560, 180, 24, 1280), (2560, 180, 48, 1280), (640, 720, 24, 0), (640, 816, 3, 320), (320, 1000, 48, 0),
+                                               (320, 1600, 24, 0), (1280, 408, 2, 0), (64, 5000, 2, 0)])
+def test_groupnorm_backward_slab_in_registers(C, rps, samples, c1):
+    """The backward slab kernel (x and dy in registers) vs autograd, plain and accumulating, and vs the two backward launches."""
+    rows = rps * samples
+    assert ops.groupnorm_slab_ok(rows, C, rps, 32, c1 or C, backward=True) and not ops.groupnorm_fused_ok(rows, C, rps, 32)
+    x = bf(rnd(rows, C, seed=1) * 2 + 0.5)
+    gamma, beta = rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.2
+    dy = bf(rnd(rows, C, seed=4))
+    xs = (x, None) if not c1 else (x[:, :c1].contiguous(), x[:, c1:].contiguous())
+    xa = x.float().requires_grad_(True)
+    yy = F.silu(F.group_norm(xa.reshape(samples, rps, C).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, C)
+    (gref,) = torch.autograd.grad(yy, xa, dy.float())
+    st = ops.groupnorm_stats(xs[0], gamma, beta, rps, x2=xs[1])
+    _, mr = ops.groupnorm_apply(xs[0], st, rps, silu=True, x2=xs[1])
+    d1, d2 = ops.groupnorm_bwd(xs[0], dy, gamma, beta, mr, rps, silu=True, x2=xs[1])
+    got = d1 if d2 is None else torch.cat([d1, d2], 1)
+    close(got, gref, 1e-2, "slab groupnorm bwd")
+    saved = dict(ops._gn_fused)
+    ops._gn_fused.update(max_bytes_slab=0)
+    try:
+        e1, e2 = ops.groupnorm_bwd(xs[0], dy, gamma, beta, mr, rps, silu=True, x2=xs[1])
+    finally:
+        ops._gn_fused.update(saved)
+    close(got, e1 if e2 is None else torch.cat([e1, e2], 1), 6e-3, "slab bwd vs two launches")
+    if not c1:
+        acc = bf(rnd(rows, C, seed=5))
+        buf = acc.clone()
+        ops.groupnorm_bwd(x, dy, gamma, beta, mr, rps, silu=True, dx1=buf, accumulate=True)
+        close(buf, gref + acc.float(), 1.2e-2, "slab groupnorm bwd accumulate")
+
+
+def test_groupnorm_slab_eligibility():
+    assert not ops.groupnorm_slab_ok(17280, 640, 17280, 32)          # a 5-D norm of the 20x36 level: 85 loads per thread
+    assert not ops.groupnorm_slab_ok(4320, 1920, 180, 32, 1280)      # 60 channels per group, 1280 + 640: a group straddles the two sources
+    assert not ops.groupnorm_slab_ok(69120, 960, 2880, 32, 640)      # 30 channels per group: 4-byte loads, 43 of them
+    assert not ops.groupnorm_slab_ok(69120, 320, 2880, 32)           # 15 narrow loads per thread: no better than the two launches
+    assert not ops.groupnorm_slab_ok(1000, 96, 100, 32)              # 3 channels per group
+    assert not ops.groupnorm_slab_ok(4320, 1280, 4320, 32)           # 22 loads per thread: a 345 KB slab, slower than the two launches
+    assert not ops.groupnorm_slab_ok(4320, 2560, 180, 32, 1240)      # a group would straddle the two sources
+    assert ops.groupnorm_slab_ok(2160, 1280, 1080, 32) and ops.groupnorm_slab_ok(4320, 2560, 180, 32, 1280)
+    assert not ops.groupnorm_slab_ok(2160, 1280, 1080, 32, backward=True)   # x and dy: 6 + 6 loads of 16 bytes do not fit
+    assert ops.groupnorm_slab_ok(17280, 640, 720, 32, backward=True)
+    x = bf(rnd(4320, 1280, seed=1))
+    with pytest.raises(RuntimeError, match="does not qualify"):
+        ops.groupnorm_fused(x, torch.ones(1280, device=DEV), torch.zeros(1280, device=DEV), 4320, slab=True)
 
 
 @pytest.mark.parametrize("C", [64, 320, 640, 1280, 1024])
