@@ -21,6 +21,8 @@ timeout 300 python tools/small_ops_bench.py > $O/${T}_hbm_kernels.txt 2>&1
 timeout 200 python tools/loss_bench.py > $O/${T}_guidance_loss.txt 2>&1
 timeout 300 python tools/quant_probe.py > $O/${T}_short_k_quantisation.txt 2>&1
 timeout 300 python tools/host_profile.py > $O/${T}_host_profile.txt 2>&1
+# GroupNorm per shape by kernel duration: the single-launch slab-in-registers kernel against statistics + apply
+bash tools/gn_probe.sh > /dev/null 2>&1; cp $O/gn_probe.txt $O/${T}_groupnorm_kernels.txt
 timeout 400 python bench.py --videos-per-gpu 2 --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_2videos.json 2> $O/${T}_bench_2videos.err
 timeout 400 python bench.py --gligen --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_gligen.json 2> $O/${T}_bench_gligen.err
 LVD_CFG_SHARED_PREFIX=0 timeout 400 python bench.py --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_no_shared_prefix.json 2> $O/${T}_bench_no_shared_prefix.err
