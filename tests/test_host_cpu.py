@@ -294,6 +294,26 @@ def test_groupnorm_chunking_rules():
     assert ops._gn_chunks(24, 180, ops._gn_min_rows(2560)) == 7   # level 2, norm over [x, skip]: one row lane per workgroup, 24-row chunks (was 2 chunks)
 
 
+def test_groupnorm_single_launch_plan_for_the_step_shapes():
+    """Which GroupNorm of the 576x320x24 step runs as ONE launch with its (sample, group) slab in registers (lvdhip_groupnorm_slab_loads /
+    lvdhip_groupnorm_bwd_slab_loads are host-side queries: no GPU needed) — and which do not, and why."""
+    from lvd_amd import hip
+    fwd, bwd = hip.lib().lvdhip_groupnorm_slab_loads, hip.lib().lvdhip_groupnorm_bwd_slab_loads
+    # (c, c1, groups, rows_per_sample) -> loads per thread
+    assert fwd(1280, 1280, 32, 1080) == 6            # 5x9 level, 5-D norm of a TemporalConvLayer: 40 channels per group, 16-byte loads
+    assert fwd(2560, 1280, 32, 180) == 2             # 10x18 level, norm over [x, skip]
+    assert fwd(640, 640, 32, 720) == 4               # 20x36 level, 2-D norm: 20 channels per group, 8-byte loads
+    assert fwd(320, 320, 32, 720) == 4               # first resnet of the 20x36 level: 10 channels per group, 4-byte loads
+    assert fwd(1280, 1280, 32, 720) == 4             # 20x36 level, norm over [x, skip] (640 + 640)
+    assert fwd(1280, 1280, 32, 4320) == 0            # 10x18 level, 5-D norm: a 345 KB slab (22 loads) loses to the two launches
+    assert fwd(320, 320, 32, 2880) == 0              # 40x72 level, 2-D norm: 15 narrow loads per thread
+    assert fwd(640, 640, 32, 17280) == 0             # 20x36 level, 5-D norm
+    assert fwd(1920, 1280, 32, 180) == 0             # 1280 + 640 channels, 60 per group: a group would straddle the two sources
+    assert fwd(960, 640, 32, 2880) == 0 and fwd(96, 96, 32, 100) == 0
+    assert bwd(640, 640, 32, 720) == 4 and bwd(2560, 1280, 32, 180) == 2 and bwd(320, 320, 32, 720) == 4
+    assert bwd(1280, 1280, 32, 1080) == 0            # x and dy: 6 + 6 loads of 16 bytes do not fit the registers of a 1024-thread workgroup
+
+
 def test_test_tokenizer_ids_do_not_depend_on_call_order():
     """The stand-in tokenizer of the test suite assigns ids from the token text alone, so two processes that see different subsets
     of a prompt list (sharded generate.py) embed the same prompt identically."""
