@@ -399,11 +399,11 @@ __global__ void ln_fwd_kernel(const lvd_ln_params p) {
 constexpr int LN_BATCH = 4;
 // YOUT = false: statistics only (p.y == NULL) — the (mean, rstd) rows a LayerNorm-folded GEMM reads (lvd_gemm_params.ln_mean_rstd)
 template <int LPR, bool YOUT = true>
-__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const lvd_ln_params p) {
+__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const lvd_ln_params p, const int nb) {
   constexpr int RPW = 64 / LPR;  // rows per wave per batch
   const int lane = threadIdx.x & 63;
   const int r = lane / LPR, c = lane % LPR;
-  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * LN_BATCH);
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * nb);
   float ga[YOUT ? 5 : 1][8], be[YOUT ? 5 : 1][8];
 #pragma unroll
   for (int j = 0; j < (YOUT ? 5 : 0); ++j) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const lvd_ln_params p)
   }
   const float inv_c = 1.f / (float)p.c;
 #pragma unroll 1
-  for (int bt = 0; bt < LN_BATCH; ++bt) {
+  for (int bt = 0; bt < nb; ++bt) {
     const long row = row0 + bt * RPW + r;
     const long rowc = row < p.rows ? row : p.rows - 1;  // clamped, not predicated (the store is)
     uint4 raw[5];
@@ -509,11 +509,11 @@ __global__ void ln_bwd_kernel(const lvd_ln_bwd_params p) {
 
 // backward counterpart of ln_fwd_rows_kernel (same row/lane mapping, gamma resident over the row batches)
 template <int LPR>
-__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const lvd_ln_bwd_params p) {
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const lvd_ln_bwd_params p, const int nb) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int r = lane / LPR, c = lane % LPR;
-  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * LN_BATCH);
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (RPW * nb);
   float ga[5][8];
 #pragma unroll
   for (int j = 0; j < 5; ++j)
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const lvd_ln_bwd_param
     }
   const float inv_c = 1.f / (float)p.c;
 #pragma unroll 1
-  for (int bt = 0; bt < LN_BATCH; ++bt) {
+  for (int bt = 0; bt < nb; ++bt) {
     const long row = row0 + bt * RPW + r;
     const long rowc = row < p.rows ? row : p.rows - 1;
     uint4 rx[5], rd[5], ra[5];
@@ -656,21 +656,36 @@ extern "C" int lvdhip_groupnorm_bwd_apply(const lvd_gn_bwd_apply_params* p, void
   return 0;
 }
 
+namespace {
+// Row batches a wave walks in sequence (gamma / beta stay in registers over them): LN_BATCH when that still leaves two workgroups per
+// CU, fewer for the short matrices of the deep levels — at 1080-8640 rows four sequential round trips per wave on 34-270 workgroups
+// were the launch (6 us for < 1 us of traffic).
+int ln_batches(int rows, int lpr) {
+  static const int forced = [] { const char* e = getenv("LVD_LN_BATCHES"); return e ? atoi(e) : 0; }();  // developer knob
+  if (forced >= 1 && forced <= LN_BATCH) return forced;
+  const int rows_per_batch_block = 4 * (64 / lpr);
+  for (int nb = LN_BATCH; nb > 1; nb /= 2)
+    if (rows / (rows_per_batch_block * nb) >= 512) return nb;
+  return 1;
+}
+}  // namespace
+
 extern "C" int lvdhip_layernorm(const lvd_ln_params* p, void* stream) {
   LVD_CHECK(p && p->x && ((p->y && p->gamma && p->beta) || p->mean_rstd), "layernorm: null pointer");  // y == NULL: statistics only
   LVD_CHECK(p->c % 8 == 0 && p->c <= 512 * LN_MAXV, "layernorm: c=%d unsupported (need c%%8==0, c<=%d)", p->c, 512 * LN_MAXV);
   hipStream_t s = (hipStream_t)stream;
   const int lpr = p->c % 40 == 0 ? p->c / 40 : 0;
   if (lpr == 8 || lpr == 16 || lpr == 32) {
-    const int rows_per_block = 4 * (64 / lpr) * LN_BATCH;
+    const int nb = ln_batches(p->rows, lpr);
+    const int rows_per_block = 4 * (64 / lpr) * nb;
     const dim3 grid((unsigned)((p->rows + rows_per_block - 1) / rows_per_block));
     if (!p->y) {
-      if (lpr == 8) hipLaunchKernelGGL((ln_fwd_rows_kernel<8, false>), grid, dim3(256), 0, s, *p);
-      else if (lpr == 16) hipLaunchKernelGGL((ln_fwd_rows_kernel<16, false>), grid, dim3(256), 0, s, *p);
-      else hipLaunchKernelGGL((ln_fwd_rows_kernel<32, false>), grid, dim3(256), 0, s, *p);
-    } else if (lpr == 8) hipLaunchKernelGGL(ln_fwd_rows_kernel<8>, grid, dim3(256), 0, s, *p);
-    else if (lpr == 16) hipLaunchKernelGGL(ln_fwd_rows_kernel<16>, grid, dim3(256), 0, s, *p);
-    else hipLaunchKernelGGL(ln_fwd_rows_kernel<32>, grid, dim3(256), 0, s, *p);
+      if (lpr == 8) hipLaunchKernelGGL((ln_fwd_rows_kernel<8, false>), grid, dim3(256), 0, s, *p, nb);
+      else if (lpr == 16) hipLaunchKernelGGL((ln_fwd_rows_kernel<16, false>), grid, dim3(256), 0, s, *p, nb);
+      else hipLaunchKernelGGL((ln_fwd_rows_kernel<32, false>), grid, dim3(256), 0, s, *p, nb);
+    } else if (lpr == 8) hipLaunchKernelGGL(ln_fwd_rows_kernel<8>, grid, dim3(256), 0, s, *p, nb);
+    else if (lpr == 16) hipLaunchKernelGGL(ln_fwd_rows_kernel<16>, grid, dim3(256), 0, s, *p, nb);
+    else hipLaunchKernelGGL(ln_fwd_rows_kernel<32>, grid, dim3(256), 0, s, *p, nb);
     LVD_LAUNCH_CHECK();
     return 0;
   }
@@ -686,11 +701,12 @@ extern "C" int lvdhip_layernorm_bwd(const lvd_ln_bwd_params* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int lpr = p->c % 40 == 0 ? p->c / 40 : 0;
   if (lpr == 8 || lpr == 16 || lpr == 32) {
-    const int rows_per_block = 4 * (64 / lpr) * LN_BATCH;
+    const int nb = ln_batches(p->rows, lpr);
+    const int rows_per_block = 4 * (64 / lpr) * nb;
     const dim3 grid((unsigned)((p->rows + rows_per_block - 1) / rows_per_block));
-    if (lpr == 8) hipLaunchKernelGGL(ln_bwd_rows_kernel<8>, grid, dim3(256), 0, s, *p);
-    else if (lpr == 16) hipLaunchKernelGGL(ln_bwd_rows_kernel<16>, grid, dim3(256), 0, s, *p);
-    else hipLaunchKernelGGL(ln_bwd_rows_kernel<32>, grid, dim3(256), 0, s, *p);
+    if (lpr == 8) hipLaunchKernelGGL(ln_bwd_rows_kernel<8>, grid, dim3(256), 0, s, *p, nb);
+    else if (lpr == 16) hipLaunchKernelGGL(ln_bwd_rows_kernel<16>, grid, dim3(256), 0, s, *p, nb);
+    else hipLaunchKernelGGL(ln_bwd_rows_kernel<32>, grid, dim3(256), 0, s, *p, nb);
     LVD_LAUNCH_CHECK();
     return 0;
   }
