@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_small_kernel(const lvd_gn_bw
 
 // backward counterpart of gn_slab_kernel: x AND dy of the slab in registers, one launch: sums of (g, g*xhat) over the slab, then
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) from what the thread holds (g is formed twice, as in the two-launch kernels).
-// gamma / beta are read from LDS at every use (volatile: in registers they, the held rows and the SiLU-gradient temporaries do not fit).
+// gamma / beta are fetched from LDS again for every row, behind a compiler fence: kept in registers across the rows they, the held rows and
+// the SiLU-gradient temporaries do not fit.  [Read one by one as volatiles they became flat loads with a full wait each.]
 template <int U, int V>
 __global__ __launch_bounds__(1024) void gn_bwd_slab_kernel(const lvd_gn_bwd_apply_params p, int OPG, int RLN, int samples) {
   constexpr int T = 1024;
@@ -311,25 +312,30 @@ __global__ __launch_bounds__(1024) void gn_bwd_slab_kernel(const lvd_gn_bwd_appl
   for (int i = t; i < cpg; i += T) { gb[0][i] = p.gamma[g * cpg + i]; gb[1][i] = p.beta[g * cpg + i]; }
   const float mean = p.mean_rstd[((long)s * p.groups + g) * 2], rstd = p.mean_rstd[((long)s * p.groups + g) * 2 + 1];
   __syncthreads();
-  const volatile float* gam = &gb[0][V * j];
-  const volatile float* bet = &gb[1][V * j];
+  const float* gam = &gb[0][V * j];
+  const float* bet = &gb[1][V * j];
   const int do_silu = p.silu;
-  auto pair = [&](uint32_t xw, uint32_t dw, int e, float& xh0, float& xh1, float& g0, float& g1) {
-    const float ga0 = gam[2 * e], ga1 = gam[2 * e + 1];
+  auto fetch = [&](float (&ga)[V], float (&be)[V]) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < V; ++e) { ga[e] = gam[e]; be[e] = bet[e]; }
+  };
+  auto pair = [&](uint32_t xw, uint32_t dw, const float* ga, const float* be, float& xh0, float& xh1, float& g0, float& g1) {
     xh0 = (bflo(xw) - mean) * rstd; xh1 = (bfhi(xw) - mean) * rstd;
     g0 = bflo(dw); g1 = bfhi(dw);
-    if (do_silu) { g0 *= silu_grad_f(xh0 * ga0 + bet[2 * e]); g1 *= silu_grad_f(xh1 * ga1 + bet[2 * e + 1]); }
-    g0 *= ga0; g1 *= ga1;
+    if (do_silu) { g0 *= silu_grad_f(xh0 * ga[0] + be[0]); g1 *= silu_grad_f(xh1 * ga[1] + be[1]); }
+    g0 *= ga[0]; g1 *= ga[1];
   };
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const float w = (live && r0 + u * RLN < rps) ? 1.f : 0.f;
-    float a1 = 0.f, a2 = 0.f;
+    float ga[V], be[V], a1 = 0.f, a2 = 0.f;
+    fetch(ga, be);
 #pragma unroll
     for (int e = 0; e < V / 2; ++e) {
       float xh0, xh1, g0, g1;
-      pair(rx[u].w[e], rd[u].w[e], e, xh0, xh1, g0, g1);
+      pair(rx[u].w[e], rd[u].w[e], ga + 2 * e, be + 2 * e, xh0, xh1, g0, g1);
       a1 += g0 + g1;
       a2 += g0 * xh0 + g1 * xh1;
     }
@@ -361,10 +367,12 @@ __global__ __launch_bounds__(1024) void gn_bwd_slab_kernel(const lvd_gn_bwd_appl
 #pragma unroll
     for (int e = 0; e < V / 2; ++e) acc.w[e] = 0;
     if (accumulate) acc = slab_load<V>(ob + (row0 + r) * ldo);
+    float ga[V], be[V];
+    fetch(ga, be);
 #pragma unroll
     for (int e = 0; e < V / 2; ++e) {
       float xh0, xh1, g0, g1;
-      pair(rx[u].w[e], rd[u].w[e], e, xh0, xh1, g0, g1);
+      pair(rx[u].w[e], rd[u].w[e], ga + 2 * e, be + 2 * e, xh0, xh1, g0, g1);
       o.w[e] = pack2bf(rstd * (g0 - m1 - xh0 * m2) + bflo(acc.w[e]), rstd * (g1 - m1 - xh1 * m2) + bfhi(acc.w[e]));
     }
     slab_store<V>(ob + (row0 + r) * ldo, o);
