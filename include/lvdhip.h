@@ -70,6 +70,11 @@ enum {
   LVD_GEMM_V_CONV_HALO = 41,
   LVD_GEMM_V_CONV_HALO_SPLITK = 45, /* channel chunks split over workgroups + deterministic slab reduction */
   LVD_GEMM_V_CONV_HALO_TAIL = 47,   /* CONV_HALO on whole rounds of the 256 CUs, CONV_HALO_SPLITK on the remaining tiles */
+  /* Persistent walker (gemm_stream.hip; only as LVD_GEMM_V_STREAM + LVD_GEMM_V_ADMA = 161): ONE 8-wave workgroup per CU walks the
+     256x320 / 256x256 tiles of the product, the three-slot ring of 32-deep K tiles runs through the tile boundaries, the epilogue's
+     stores are never waited for and the last partial round is cut into 128-row half tiles.  Plain single-source loader, K % 32 == 0,
+     K >= 128, bf16 output (bias, alpha, residual, GEGLU, LayerNorm fold); anything else runs RING256W + ADMA. */
+  LVD_GEMM_V_STREAM = 61,
   /* + LVD_GEMM_V_ADMA on a RING128 / RING256N / RING256W / RING128x320 / SPLITK / SPLITK_WIDE / *_TAIL variant: the same
      geometry with its LDS-DMA issued from buffer descriptors in inline assembly, counted waits that really leave tiles in
      flight, bias row staged by the DMA engine (plain loader, K % 32 == 0; anything else runs the base variant) */

@@ -315,6 +315,8 @@ int launch_gemm(const lvd_gemm_params* p, dim3 grid, hipStream_t s) {
 int lvd_gemm_ring_dispatch(const lvd_gemm_params* p, void* stream, int geometry);  // gemm_ring.hip
 bool lvd_conv_halo_eligible(const lvd_gemm_params* p);                               // conv_halo.hip
 int lvd_conv_halo_dispatch(const lvd_gemm_params* p, void* stream, int plan);
+bool lvd_gemm_stream_eligible(const lvd_gemm_params* p);                             // gemm_stream.hip
+int lvd_gemm_stream_dispatch(const lvd_gemm_params* p, void* stream, int nsw);
 
 namespace {
 
@@ -363,6 +365,16 @@ int run_variant(const lvd_gemm_params* p, void* stream, int v) {
       return lvd_conv_halo_dispatch(p, stream, v == LVD_GEMM_V_CONV_HALO ? 0 : (v == LVD_GEMM_V_CONV_HALO_SPLITK ? 1 : 2));
     if (v == LVD_GEMM_V_CONV_HALO_TAIL) return run_with_tail(p, stream, LVD_GEMM_V_RING256W_TAIL);
     v = v == LVD_GEMM_V_CONV_HALO ? LVD_GEMM_V_RING256W : LVD_GEMM_V_SPLITK_WIDE;
+  }
+  // persistent walker over the 8-wave ping-pong tiles (gemm_stream.hip; asm-DMA only: 161); products it cannot take run RING256W + ADMA
+  if (v == LVD_GEMM_V_STREAM) {
+    if (adma != 100) return 3;
+    static const int nsw = [] {  // developer A/B: LVD_STREAM_NSW=0 makes the first wait behind an epilogue cover every store
+      const char* e = getenv("LVD_STREAM_NSW");
+      return e ? atoi(e) : 1;
+    }();
+    if (lvd_gemm_stream_eligible(p)) return lvd_gemm_stream_dispatch(p, stream, nsw);
+    v = LVD_GEMM_V_RING256W;
   }
   const int a100 = adma ? 100 : 0;  // geometries without a 64-deep form take the 32-deep asm-DMA one
   if (v >= 5 && v <= 8) return lvd_gemm_ring_dispatch(p, stream, v - 5 + (v <= 6 ? (v == 5 ? adma : a100) : 0));

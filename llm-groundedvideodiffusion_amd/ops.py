@@ -74,7 +74,7 @@ class ConvGeom:
 # (M, N, K, loader): short-K linears favour many small workgroups, long-K convs the LDS-DMA ring, and the
 # 1-workgroup-per-CU 256-wide tiles only pay when the grid quantises well.  The first call of a new shape times the
 # candidates on a scratch output (HIP events on the launch stream) and pins the winner for the process.
-GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117, 211, 205, 209, 217)  # 100 + v: asm-DMA instantiation of ring variant v; 200 + v: 64-deep K tiles
+GEMM_CANDIDATES = (10, 1, 5, 9, 11, 14, 17, 105, 109, 111, 117, 161, 211, 205, 209, 217)  # 100 + v: asm-DMA instantiation of ring variant v; 200 + v: 64-deep K tiles; 161: persistent walker (gemm_stream.hip)
 SPLITK_VARIANT = 20
 SPLITK_WIDE_VARIANT = 25
 TAIL_VARIANTS = (31, 37, 120, 125, 131, 137, 225, 231, 220)  # whole rounds on the wide geometry + split-K remainder (gemm.hip run_with_tail); need the workspace
@@ -95,6 +95,7 @@ def _splitk_workspace(dev, nbytes):
     if ws is None:
         ws = _splitk_ws[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev)
     return ws
+_debug_ws = None  # developer probes (tools/stream_trace.py): a tensor handed to every launch as p.ws whatever the product's own need
 _gemm_choice = {}
 _autotune = {"enabled": True, "min_flops": 2e9}
 _EXCLUDE = tuple(int(v) for v in os.environ.get("LVD_GEMM_EXCLUDE", "").split(",") if v)  # developer knob: variants the tuner must not try
@@ -215,6 +216,8 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     if need.value:
         ws = _splitk_workspace(a1.device, need.value)  # one fixed-size buffer per device, shared by all launches of the stream
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    if _debug_ws is not None:
+        p.ws, p.ws_bytes = _debug_ws.data_ptr(), _debug_ws.numel() * 4
     if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"]:
         # everything a candidate's eligibility or cost depends on: the conv image (the LDS-resident tap GEMM needs W <= 87), the temporal
         # geometry (its tile is pixels x all frames) and a temb row-bias (the asm-DMA forms do not take one)

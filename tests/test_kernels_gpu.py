@@ -450,7 +450,7 @@ def test_gemm_row_range(variant):
     assert (outc[:500] == 0).all()
 
 
-@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37, 41, 47, 105, 109, 111, 117, 131, 137, 211, 231])
+@pytest.mark.parametrize("variant", [5, 11, 17, 31, 37, 41, 47, 105, 109, 111, 117, 131, 137, 161, 211, 231])
 def test_gemm_many_tiles(variant):
     """Grids of several rounds of tiles (tail-aware variants split them into whole rounds + a K-split remainder): short and
     ragged K, ragged M, full epilogue, GEGLU, conv loader."""
@@ -480,7 +480,7 @@ def _ln_fold_operands(W, bias, gamma, beta):
     return Wp, Wp.float().sum(1).contiguous(), ((bias if bias is not None else 0) + W.float() @ beta).contiguous()
 
 
-@pytest.mark.parametrize("variant", [0, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231, 20, 25, 205, 209, 217, 220])
+@pytest.mark.parametrize("variant", [0, 105, 106, 109, 111, 117, 120, 125, 131, 137, 161, 211, 225, 231, 20, 25, 205, 209, 217, 220])
 @pytest.mark.parametrize("M,N,K", [(700, 320, 320), (3000, 960, 640), (513, 2560, 320)])
 def test_gemm_layernorm_fold(variant, M, N, K):
     """LayerNorm(x) W^T + b as ONE product on the raw rows (lvd_gemm_params.ln_mean_rstd): every asm-DMA ring geometry and the K-split
@@ -509,7 +509,7 @@ def test_gemm_layernorm_fold(variant, M, N, K):
     close(out, two, 1.2e-2, f"v{variant} fold vs LayerNorm + GEMM")
 
 
-@pytest.mark.parametrize("variant", [0, 105, 111, 211])
+@pytest.mark.parametrize("variant", [0, 105, 111, 161, 211])
 def test_gemm_layernorm_fold_geglu(variant):
     from lvd_amd.weights import interleave_geglu
     M, K, H = 900, 320, 1280
@@ -532,7 +532,7 @@ def test_gemm_layernorm_fold_rejects_kernels_without_it():
             ops.gemm(x, W, ln_stats=mr, ln_colsum=cs, variant=v)
 
 
-@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47, 105, 106, 109, 111, 117, 120, 125, 131, 137, 211, 225, 231])
+@pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47, 105, 106, 109, 111, 117, 120, 125, 131, 137, 161, 211, 225, 231])
 def test_gemm_every_tile_geometry(variant):
     """Each pinned tile geometry (include/lvdhip.h LVD_GEMM_V_*) against the same fp32 references: plain with full
     epilogue, two-source concat, GEGLU, 3x3 conv (stride 2, upsample, concat), temporal conv, transposed conv."""
@@ -697,6 +697,76 @@ def test_gemm_split_k(SPLITK):
     close(out, reft, 6e-3, f"v{SPLITK} split-K tconv")
 
 
+
+STREAM_CASES = [(700, 320, 320, "plain"), (256 * 300 + 37, 320, 352, "res"), (256 * 540, 320, 320, "res"), (256 * 270 + 129, 960, 320, "plain"),
+                (256 * 135, 1920, 640, "plain"), (3000, 960, 640, "ln"), (256 * 260 + 5, 960, 320, "ln"), (70000, 320, 128, "ln"),
+                (256 * 270, 2560, 320, "geglu"), (256 * 100 + 9, 1280, 320, "lngeglu"), (256 * 300 + 77, 512, 512, "res"),
+                (256 * 300 + 77, 1536, 512, "ln"), (256 * 280 + 200, 640, 640, "res"), (256 * 600, 336, 160, "plain"), (256 * 257 + 1, 320, 320, "alpha")]
+
+
+@pytest.mark.parametrize("M,N,K,kind", STREAM_CASES)
+def test_gemm_stream_walker_equals_the_one_shot_ring_bit_for_bit(M, N, K, kind):
+    """Persistent walker (variant 161, gemm_stream.hip): one workgroup per CU walks the 256x320 / 256x256 tiles, the K-tile ring runs through
+    the tile boundaries, the stores are never waited for, the last partial round is cut into 128-row half tiles.  K order per accumulator
+    and epilogue arithmetic are those of the one-shot 32-deep ring (variant 111), so the two must agree BIT FOR BIT — for every epilogue
+    (bias, alpha + residual, GEGLU, LayerNorm fold, both together), one item per workgroup, many items, ragged M and N, both tile widths,
+    and with / without the half-tile tail (tile counts 2R <= G and 2R > G past whole rounds of 256 workgroups); four launches bit-equal."""
+    from lvd_amd.weights import interleave_geglu
+    x = rnd(M, K, seed=1)
+    if "ln" in kind:
+        x[::3] += 4.0
+    x = bf(x)
+    W, bias = bf(rnd(N, K, seed=2, scale=0.05)), rnd(N, seed=3)
+    if kind in ("plain", "res", "alpha"):
+        ref = x.float() @ W.float().T + bias
+        w_, kw = W, dict(bias=bias)
+        if kind != "plain":
+            kw["res"] = bf(rnd(M, N, seed=7))
+            if kind == "alpha":
+                kw["alpha"] = 0.5
+            ref = kw["res"].float() + kw.get("alpha", 1.0) * ref
+    elif kind == "geglu":
+        wi, bi = interleave_geglu(W, bias)
+        w_, kw = wi, dict(bias=bi, act=ops.ACT_GEGLU)
+        proj = x.float() @ W.float().T + bias
+        ref = proj[:, :N // 2] * F.gelu(proj[:, N // 2:])
+    else:
+        gamma, beta = 1.0 + 0.3 * rnd(K, seed=4), 0.2 * rnd(K, seed=5)
+        proj = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.float().T + bias
+        mr = ops.layernorm_stats(x)
+        if kind == "lngeglu":
+            wi, bi = interleave_geglu(W, bias)
+            w_, colsum, bp = _ln_fold_operands(wi, bi, gamma, beta)
+            ref, kw = proj[:, :N // 2] * F.gelu(proj[:, N // 2:]), dict(bias=bp, act=ops.ACT_GEGLU, ln_stats=mr, ln_colsum=colsum)
+        else:
+            w_, colsum, bp = _ln_fold_operands(W, bias, gamma, beta)
+            ref, kw = proj, dict(bias=bp, ln_stats=mr, ln_colsum=colsum)
+    one_shot = ops.gemm(x, w_, variant=111, **kw)
+    out = ops.gemm(x, w_, variant=161, **kw)
+    close(out, ref, 1.2e-2, f"stream {kind} {M}x{N}x{K}")
+    assert torch.equal(out, one_shot), f"stream {kind} {M}x{N}x{K}: {(out != one_shot).sum().item()} elements differ from variant 111"
+    for rep in range(3):
+        assert torch.equal(out, ops.gemm(x, w_, variant=161, **kw)), f"stream {kind} {M}x{N}x{K}: run-to-run difference (race)"
+
+
+def test_gemm_stream_falls_back_for_products_it_cannot_take():
+    """Two sources, a temb row-bias, fp32 output, accumulate, a row range and K < 128 run the one-shot RING256W + ADMA kernels under code 161."""
+    M, N, K = 1000, 320, 320
+    a, w, bias = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05)), rnd(N, seed=3)
+    ref = a.float() @ w.float().T + bias
+    close(ops.gemm(a[:, :192].contiguous(), w, a2=a[:, 192:].contiguous(), bias=bias, variant=161), ref, 6e-3, "161 two sources")
+    rowb = rnd(4, N, seed=4)
+    close(ops.gemm(a, w, bias=bias, rowbias=rowb, rows_per_sample=250, variant=161), ref + rowb.repeat_interleave(250, 0), 6e-3, "161 rowbias")
+    close(ops.gemm(a, w, bias=bias, out_fp32=True, variant=161), ref, 2e-3, "161 fp32 out")
+    acc = bf(rnd(M, N, seed=5))
+    close(ops.gemm(a, w, bias=bias, out=acc.clone(), accumulate=True, variant=161), ref + acc.float(), 6e-3, "161 accumulate")
+    close(ops.gemm(a[:, :96].contiguous(), w[:, :96].contiguous(), bias=bias, variant=161), a[:, :96].float() @ w[:, :96].float().T + bias, 6e-3, "161 K=96")
+    out = torch.full((M, N), 7.0, device=DEV).bfloat16()
+    ops.gemm(a, w, bias=bias, out=out, variant=161, m_begin=300)
+    close(out[300:], ref[300:], 6e-3, "161 row range")
+    assert (out[:300].float() == 7.0).all()
+
+
 def _start_cotenant(seconds):
     """A second process that loops over GroupNorm / LayerNorm / small GEMM / SiLU launches on this GPU; returns once its first launch
     has run (it prints READY), i.e. what follows is measured next to a live co-tenant — no fixed sleep."""
@@ -720,7 +790,7 @@ def test_gemm_bit_reproducible_next_to_a_cotenant_process():
         M, N, K = 69120, 1536, 512
         a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
         bias = rnd(N, seed=3)
-        for v in (11, 111, 131, 211, 231, 225, 205, 209, 217):
+        for v in (11, 111, 131, 161, 211, 231, 225, 205, 209, 217):
             ref = ops.gemm(a, w, bias=bias, variant=v)
             for rep in range(12):
                 assert torch.equal(ops.gemm(a, w, bias=bias, variant=v), ref), f"variant {v}: launch {rep} differs from the first one"
@@ -790,7 +860,7 @@ def test_every_hand_synchronised_kernel_is_bit_reproducible_next_to_a_cotenant_p
         Wp, colsum, bp = _ln_fold_operands(W, None, gamma, beta)
         same("layernorm_stats", lambda: (ops.layernorm_stats(xa),))
         mr = ops.layernorm_stats(xa)
-        for v in (105, 109, 111, 117, 211, 231):
+        for v in (105, 109, 111, 117, 161, 211, 231):
             same(f"layernorm-folded gemm v{v}", lambda: (ops.gemm(xa, Wp, bias=bp, ln_stats=mr, ln_colsum=colsum, variant=v),))
         # GroupNorm: statistics partials + the apply kernels that fold them (2-D and 5-D sample sizes), forward and backward
         gam, bet = 1 + 0.1 * rnd(C, seed=15), 0.1 * rnd(C, seed=16)
