@@ -38,6 +38,11 @@ from lvd_amd.weights import UNetConfig, synthetic_state_dict  # noqa: E402
 TF_CFG_FWD = 42.79          # unguided step: CFG forward, B=2
 TF_GUIDANCE_ITER = 31.8     # 15.92 fwd (to the last key) + ~15.92 dgrad backward
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# What the shared CFG prefix (engine.forward(cfg_pairs=True)) does NOT execute a second time, per video: conv_in 0.0016 + transformer_in 0.777
+# (per token 2*320*512 + 2 x (2*512*1536 + 2*512*512 + 4*24*512) + 2*512*4096 + 2*2048*512 + 2*512*320) + the first ResnetBlock2D 0.2548
+# (two 3x3 convs 320 -> 320) + the first TemporalConvLayer 0.1699 (four (3,1,1) convs) + proj_in / to_qkv / 2880-key self-attention / to_out of
+# the first spatial transformer 0.3256 (per token 2*320*320 + 2*320*960 + 4*2880*320 + 2*320*320), all x 69120 token rows
+TF_CFG_SHARED_PREFIX = 1.53
 GUIDANCE_KEYS = [("down", 1, 0, 0), ("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 2, 0)]  # generation/lvd.py:66-73
 FRAMES, LAT_H, LAT_W = 24, 40, 72
 
@@ -412,7 +417,7 @@ def main():
         dom = max(agg, key=lambda m: agg[m][1])
         n, secs, fl = agg[dom]
         ach = fl / secs / 1e12
-        tfile = next((f for f in ("r04_gemm_traffic.json", "r03_gemm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_gemm_traffic.json")
+        tfile = next((f for f in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_gemm_traffic.json")
         traffic, tnote = None, f"no profiles/{tfile} next to bench.py"
         tpath = os.path.join(ROOT, "profiles", tfile)
         tsource = f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes: tools/traffic_passes.sh; NOT measured in this run)"
@@ -468,6 +473,7 @@ def main():
         tf_cfg = 52.88 if args.gligen else TF_CFG_FWD  # CFG forward with the fusers enabled
         step_tf = V * (tf_cfg + TF_GUIDANCE_ITER)
         tf_cfg = V * tf_cfg
+        skipped_tf = V * TF_CFG_SHARED_PREFIX if engine.cfg_shared_prefix else 0.0
         mean40 = (10 * ms_guided + 30 * ms_unguided) / 40
         out = {
             "metric": "denoise-step frames/sec, LVD-Zeroscope 576x320x24 w/ guidance" + (" + GLIGEN adapters" if args.gligen else "")
@@ -487,13 +493,18 @@ def main():
             "step_algorithmic_tflop": step_tf,
             "step_mfma_frac": round(step_tf / (ms_guided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "unguided_mfma_frac": round(tf_cfg / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
+            # the same with the FLOPs the timed region really executes (the shared CFG prefix counted once per video): the figure to compare
+            # between rounds; *_algorithmic keeps the reference module's count (the prefix twice)
+            "step_executed_tflop": round(step_tf - skipped_tf, 2),
+            "step_mfma_frac_executed": round((step_tf - skipped_tf) / (ms_guided * 1e-3) / PEAK_BF16_TFLOPS, 4),
+            "unguided_mfma_frac_executed": round((tf_cfg - skipped_tf) / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "loss_finite": finite,
             "guided_step_is": "guidance.hip_latent_backward_guidance (one iteration; the returned loss tensor is carried into the next step, whose entry check waits for its pinned host copy) + CFG forward + fused CFG/DPM update",
             "cfg_shared_prefix": bool(engine.cfg_shared_prefix),
             "cfg_shared_prefix_note": "the (uncond, cond) items of the CFG batch are the SAME latents (reference: torch.cat([latents] * 2)) and stay identical "
                                       "until the first text-dependent layer; that prefix (conv_in, transformer_in, first resnet / temporal conv / spatial self-"
-                                      "attention) runs once per sample and is duplicated there.  step_algorithmic_tflop still counts it twice, as the reference "
-                                      "module does; LVD_CFG_SHARED_PREFIX=0 disables it",
+                                      "attention) runs once per sample and is duplicated there.  step_algorithmic_tflop counts it twice, as the reference "
+                                      "module does; step_executed_tflop / *_mfma_frac_executed count it once; LVD_CFG_SHARED_PREFIX=0 disables it",
             "gemm_autotune_table": table_loaded, "rccl_ranks_seen": rccl_seen,
             "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,

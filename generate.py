@@ -154,14 +154,26 @@ def main(argv=None):
             return
         jobs = list(pending)
         pending.clear()
-        if len(jobs) == 1 and args.videos_per_gpu <= 1:
-            j = jobs[0]
-            from lvd_amd.generation import _common
-            _common.configure(img_dir=j["img_dir"])
-            run(j["parsed_layout"], seed=j["seed"], repeat_ind=j["repeat_ind"], **run_kwargs)
-        else:
-            generation.run_many(jobs, **run_kwargs)
+        try:
+            if len(jobs) == 1 and args.videos_per_gpu <= 1:
+                j = jobs[0]
+                from lvd_amd.generation import _common
+                _common.configure(img_dir=j["img_dir"])
+                run(j["parsed_layout"], seed=j["seed"], repeat_ind=j["repeat_ind"], **run_kwargs)
+            else:
+                generation.run_many(jobs, **run_kwargs)
+        except Exception:
+            # the whole batch was in the loop that failed: say which (prompt directory, repeat) pairs are lost with it
+            print("***dropped with the failing batch: " + ", ".join(f"{j['img_dir']} repeat {j['repeat_ind']}" for j in jobs) + "***")
+            raise
         generated += len(jobs)
+
+    def drop_jobs_of(img_dir):
+        """A prompt failed before / while queueing: only ITS queued jobs go; jobs of earlier prompts still waiting for a full batch stay."""
+        gone = [j for j in pending if j["img_dir"] == img_dir]
+        if gone:
+            pending[:] = [j for j in pending if j["img_dir"] != img_dir]
+            print("***dropped: " + ", ".join(f"{j['img_dir']} repeat {j['repeat_ind']}" for j in gone) + "***")
 
     try:
         for regenerate_ind in range(args.regenerate):
@@ -200,12 +212,12 @@ def main(argv=None):
                 except RuntimeError:
                     print("***RuntimeError: might run out of memory, skipping the current one***")
                     print(traceback.format_exc())
-                    pending.clear()
+                    drop_jobs_of(img_dir)
                     time.sleep(1)
                 except Exception as e:  # noqa: BLE001
                     print(f"***Error: {e}***")
                     print(traceback.format_exc())
-                    pending.clear()
+                    drop_jobs_of(img_dir)
                     if args.no_continue_on_error:
                         raise
                 ind += 1

@@ -333,7 +333,7 @@ typedef struct {
   float scale;
   const int32_t* tok_ids; int32_t ntok;
   const float* probs; const float* dprobs; const float* lse;
-  lvd_bf16* dq; int32_t lddq;           /* out [frames*P, heads*64] */
+  lvd_bf16* dq; int32_t lddq;           /* out [frames*P, heads*64]; 16-byte aligned, lddq % 8 == 0 (rows are written as 16-byte stores) */
   /* layouts with more object tokens than one launch holds run in chunks of tokens; dQ is linear in them and is summed in fp32:
      acc_mode 0: dq = value (one launch, acc32 unused)   1: acc32 = value   2: acc32 += value   3: dq = bf16(acc32 + value) */
   float* acc32; int32_t ldacc; int32_t acc_mode;

@@ -444,9 +444,9 @@ extern "C" int lvdhip_gemm(const lvd_gemm_params* p, void* stream) {
               "gemm: bad conv dims");
   LVD_CHECK(p->m_begin >= 0 && p->m_begin < p->M, "gemm: m_begin %d outside [0, M=%d)", p->m_begin, p->M);
   if (p->ln_mean_rstd)
-    LVD_CHECK(p->ln_colsum && p->mode == LVD_A_PLAIN && !p->out_fp32 && !p->rowbias && !p->res && !p->accumulate && !p->a2 && p->N % 16 == 0 &&
+    LVD_CHECK(p->ln_colsum && p->bias && p->mode == LVD_A_PLAIN && !p->out_fp32 && !p->rowbias && !p->res && !p->accumulate && !p->a2 && p->N % 16 == 0 &&
                   p->ldc % 8 == 0 && p->K % 32 == 0 && (reinterpret_cast<uintptr_t>(p->out) & 15) == 0,
-              "gemm: a LayerNorm-folded product needs ln_colsum, the plain single-source loader, K%%32==0, no residual / accumulate / temb row-bias "
+              "gemm: a LayerNorm-folded product needs ln_colsum, a bias row (b + W beta: the folded epilogue always reads it), the plain single-source loader, K%%32==0, no residual / accumulate / temb row-bias "
               "and a 16-byte addressable bf16 output (N%%16, ldc%%8)");
   static const int variant = [] {  // developer knob for A/B runs (tools/gemm_bench.py); read once, thread-safe initialisation
     const char* e = getenv("LVD_GEMM_VARIANT");

@@ -771,6 +771,9 @@ int check_dq(const lvd_ca_dq_params* p) {
   LVD_CHECK(p && p->q && p->k && p->tok_ids && p->probs && p->dprobs && p->lse && p->dq, "ca_dq: null pointer");
   LVD_CHECK(p->ntok > 0 && p->ntok <= MAXTOK, "ca_dq: ntok=%d outside 1..%d", p->ntok, MAXTOK);
   LVD_CHECK(p->acc_mode >= 0 && p->acc_mode <= 3 && (p->acc_mode == 0 || (p->acc32 && p->ldacc % 4 == 0)), "ca_dq: acc_mode %d needs an fp32 accumulator", p->acc_mode);
+  // the bf16 dQ rows leave as 16-byte stores at dq + row * lddq + head * 64 + 8 * k (acc_mode 0 and the closing pass of acc_mode 3)
+  if (p->acc_mode == 0 || p->acc_mode == 3)
+    LVD_CHECK(p->lddq % 8 == 0 && (reinterpret_cast<uintptr_t>(p->dq) & 15) == 0, "ca_dq: dq must be 16-byte aligned with lddq %% 8 == 0 (lddq=%d)", p->lddq);
   return 0;
 }
 }  // namespace

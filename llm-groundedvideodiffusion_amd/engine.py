@@ -602,7 +602,11 @@ class HipUNet3D:
             B = 2 * B  # batch of the result and of everything behind the split
         assert text.B == B
         if torch.is_tensor(timestep):
-            t = timestep.to(self.dev, torch.float32).reshape(-1).expand(B).contiguous()
+            tt = timestep.to(self.dev, torch.float32).reshape(-1)
+            # the shared CFG prefix runs on V samples and reads temb row v for sample v — item v's row, not item 2v's: only the same
+            # timestep for every item (what every caller passes; the reference feeds ONE t per step) makes those rows interchangeable
+            assert not pending or tt.numel() == 1 or bool((tt == tt[0]).all()), "cfg_pairs: one timestep for all items (scalar or all entries equal)"
+            t = tt.expand(B).contiguous()
         else:
             t = torch.full((B,), float(timestep), dtype=torch.float32, device=self.dev)
         temb = ops.timestep_embedding(t, boc[0])

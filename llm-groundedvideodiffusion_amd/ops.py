@@ -175,6 +175,7 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     _chk_bf16(a1, a2, w, res)
     _chk_f32(ln_stats, ln_colsum)
     assert (ln_stats is None) == (ln_colsum is None)
+    assert ln_stats is None or bias is not None, "a LayerNorm-folded product needs its bias row (b + W beta): the folded epilogue always reads it"
     _chk_f32(bias)
     _chk_f32_rows(rowbias)  # may be a column range of a wider matrix (engine: all temb projections of a forward are one product)
     N, K = w.shape if (n is None or k is None) else (n, k)

@@ -123,7 +123,12 @@ def test_cfg_shared_prefix_equals_the_duplicated_batch():
             assert shared.shape == full.shape == (2 * V, 4, Fr, 16, 16)
             err = ((shared - full).norm() / full.norm()).item()
             print(f"gated={gated} V={V}: shared-prefix vs duplicated batch rel-L2 {err:.2e}")
-            assert err < 4e-2, err  # the batch-consistency bound of test_gated_full_size_properties: bf16 rounding of other tile geometries
+            # NOT bit-equal, at any V (tests/probes/shared_prefix_probe.py: every element differs): the prefix runs at half the rows, i.e. with
+            # other tile geometries, K-split plans and GroupNorm chunkings, and those bf16 roundings pass through the rest of the random-weight
+            # network.  Measured 1.9e-2 (V = 1) ... 2.2e-2 (V = 2, gated) on this topology — two bf16 runs of one function, about sqrt(2) x the
+            # distance of either from the fp32 oracle (1.7e-2) — hence 4e-2 = measured x 2; the oracle comparison of the shared-prefix path itself
+            # is tests/test_full_topology_gpu.py::test_forward_cfg_shared_prefix_vs_oracle_of_the_duplicated_batch (3e-2)
+            assert err < 4e-2, err
             assert ((shared[0] - shared[1]).norm() / shared.norm()).item() > 1e-3  # the halves really differ (other text)
             net.cfg_shared_prefix = False
             assert torch.equal(net.forward_cfg(lat, 500, text=text, gligen=gl), full)  # the knob: exactly the duplicated batch
