@@ -218,6 +218,7 @@ def main():
                          "run and rank; shapes the table does not hold are tuned on first use")
     ap.add_argument("--retune", action="store_true", help="ignore the table and time the candidates again (--save_autotune_table writes the result)")
     ap.add_argument("--save_autotune_table", default=None)
+    ap.add_argument("--guidance-one-by-one", action="store_true", help="throughput mode A/B: the V guidance passes as V batch-1 passes (round 4) instead of one batch-V pass")
     ap.add_argument("--videos-per-gpu", type=int, default=1, help="throughput mode, NOT the headline: V independent (prompt, seed) samples per GPU, "
                     "their CFG forwards batched (B = 2V); guidance stays one recorded pass per sample")
     args = ap.parse_args()
@@ -282,6 +283,7 @@ def main():
         assert not args.gligen, "--videos-per-gpu with --gligen is not wired"
         text_cfg_all = engine.encode_text(torch.cat([ehs] + [e for _, e in more]))
         text_cond_more = [engine.encode_text(e[1:2]) for _, e in more]
+        text_cond_all = engine.encode_text(torch.cat([ehs[1:2]] + [e[1:2] for _, e in more]))  # the V cond embeddings: one batch-V guidance pass
         x0_prev_more = [torch.zeros_like(l) for l, _ in more]
     bboxes, positions = demo_layout()
     gligen = None
@@ -321,13 +323,22 @@ def main():
         t = int(sched.timesteps[i])
         # the carried loss is the tensor the previous guided step returned (controllable_pipeline_text_to_video_synth.py keeps `loss` across
         # steps): its entry check waits for the pinned-memory copy queued behind the previous backward, so that wait is inside the timed region
-        new, loss = guidance.hip_latent_backward_guidance(sched, engine, text_cond, i, bboxes, positions, t, latents, state["loss"], **gkw)
-        latents.copy_(new)
-        state["loss"] = loss
-        for v, ((l, _), tc) in enumerate(zip(more, text_cond_more if V > 1 else [])):
-            nl, lv = guidance.hip_latent_backward_guidance(sched, engine, tc, i, bboxes, positions, t, l, state["loss_more"][v], **gkw)
-            l.copy_(nl)
-            state["loss_more"][v] = lv
+        if V > 1 and not args.guidance_one_by_one:
+            # what pipeline.sample_many runs for V samples with the stock guidance function: ONE recorded forward / backward of batch V
+            lats, losses = guidance.hip_latent_backward_guidance_many(sched, engine, text_cond_all, i, [bboxes] * V, [positions] * V, t,
+                                                                      [latents] + [l for l, _ in more], [state["loss"]] + state["loss_more"], **gkw)
+            for dst, new in zip([latents] + [l for l, _ in more], lats):
+                dst.copy_(new)
+            state["loss"], state["loss_more"] = losses[0], list(losses[1:])
+            loss = losses[0]
+        else:
+            new, loss = guidance.hip_latent_backward_guidance(sched, engine, text_cond, i, bboxes, positions, t, latents, state["loss"], **gkw)
+            latents.copy_(new)
+            state["loss"] = loss
+            for v, ((l, _), tc) in enumerate(zip(more, text_cond_more if V > 1 else [])):
+                nl, lv = guidance.hip_latent_backward_guidance(sched, engine, tc, i, bboxes, positions, t, l, state["loss_more"][v], **gkw)
+                l.copy_(nl)
+                state["loss_more"][v] = lv
         if V > 1:
             cfg_all(i)
         else:
@@ -499,7 +510,9 @@ def main():
             "step_mfma_frac_executed": round((step_tf - skipped_tf) / (ms_guided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "unguided_mfma_frac_executed": round((tf_cfg - skipped_tf) / (ms_unguided * 1e-3) / PEAK_BF16_TFLOPS, 4),
             "loss_finite": finite,
-            "guided_step_is": "guidance.hip_latent_backward_guidance (one iteration; the returned loss tensor is carried into the next step, whose entry check waits for its pinned host copy) + CFG forward + fused CFG/DPM update",
+            "guided_step_is": ("guidance.hip_latent_backward_guidance_many (the V guidance passes as ONE recorded forward / backward of batch V, per-sample layouts and losses, as pipeline.sample_many runs them)"
+                               if V > 1 and not args.guidance_one_by_one else "guidance.hip_latent_backward_guidance")
+                              + " (one iteration; the returned loss tensor is carried into the next step, whose entry check waits for its pinned host copy) + CFG forward + fused CFG/DPM update",
             "cfg_shared_prefix": bool(engine.cfg_shared_prefix),
             "cfg_shared_prefix_note": "the (uncond, cond) items of the CFG batch are the SAME latents (reference: torch.cat([latents] * 2)) and stay identical "
                                       "until the first text-dependent layer; that prefix (conv_in, transformer_in, first resnet / temporal conv / spatial self-"

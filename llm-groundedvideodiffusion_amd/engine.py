@@ -221,6 +221,12 @@ class HipUNet3D:
         kv = {p: ops.gemm(x, self.w[p + ".to_kv.weight"]) for p in self.cross_layers}
         return TextCache(x, kv, B, nt)
 
+    @staticmethod
+    def text_subset(text: TextCache, items):
+        """TextCache of the listed batch items (copies of their rows: a guidance batch that lost a sample to its loss threshold)."""
+        idx = torch.cat([torch.arange(i * text.ntext, (i + 1) * text.ntext) for i in items]).to(text.tokens.device)
+        return TextCache(text.tokens.index_select(0, idx), {p: kv.index_select(0, idx) for p, kv in text.kv.items()}, len(items), text.ntext)
+
     # ------------------------------------------------------------------ primitive ops with tape hooks
     def _linear(self, x, name, *, tape, res=None, bias=True, x2=None, alpha=1.0, act=ops.ACT_NONE, out_fp32=False):
         """x: token matrix, or an LnRef (the product then runs on the raw rows with the LayerNorm folded in)."""

@@ -123,7 +123,7 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
 
 
 def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_weight, com_loss_scale, loss_partial, want_dq,
-               use_ratio_based_loss, attn_sync_weight, boxdiff_loss_scale, boxdiff_normed, boxdiff_L, _acc=None):
+               use_ratio_based_loss, attn_sync_weight, boxdiff_loss_scale, boxdiff_normed, boxdiff_L, _acc=None, dq_out=None):
     """The three parameter blocks of one key (probabilities, selection / loss, dQ) and the buffers they point into (`keep`)."""
     dev = q.device
     P = layout.H * layout.W
@@ -151,7 +151,11 @@ def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_
     c = None
     if want_dq:
         acc32, mode = _acc if _acc is not None else (None, 0)
-        dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev) if mode in (0, 3) else None
+        if dq_out is not None:  # the caller's rows of a larger dQ matrix (several samples recorded in one forward)
+            assert mode == 0 and dq_out.shape == q.shape and dq_out.dtype == torch.bfloat16 and dq_out.stride(1) == 1
+            dq = dq_out
+        else:
+            dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.bfloat16, device=dev) if mode in (0, 3) else None
         c = hip.CaDqParams()
         c.q, c.ldq, c.k, c.ldk = a.q, a.ldq, a.k, a.ldk
         c.frames, c.heads, c.P, c.ntext, c.scale = frames, heads, P, ntext, 0.125
@@ -169,21 +173,29 @@ def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_
 
 def ca_energy_loss_and_dq_all_keys(items, frames, *, ntext, grad_scale, fg_weight, bg_weight, com_loss_scale, **loss_options):
     """Every key of a guidance iteration in ONE launch per stage (probabilities / selection + loss / dQ: 3 launches instead of 3 per key;
-    csrc/guidance_loss.hip *_multi).  `items`: (q, k, heads, layout, loss_partial slice) per key.  Same bits as the key-by-key calls.
-    Layouts with more object tokens than a launch holds (chunked dQ accumulation) take the key-by-key path."""
-    if len(items) > hip.CA_MAX_KEYS or any(lay.ntok > MAX_TOKENS_PER_LAUNCH for _, _, _, lay, _ in items):
-        return [ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
-                                      com_loss_scale=com_loss_scale, loss_partial=part, **loss_options) for q, k, heads, lay, part in items]
+    csrc/guidance_loss.hip *_multi).  `items`: (q, k, heads, layout, loss_partial slice[, dq rows to write]) per key.  Same bits as the
+    key-by-key calls.  Layouts with more object tokens than a launch holds (chunked dQ accumulation) take the key-by-key path."""
+    items = [it if len(it) == 6 else (*it, None) for it in items]
+    if len(items) > hip.CA_MAX_KEYS or any(lay.ntok > MAX_TOKENS_PER_LAUNCH for _, _, _, lay, _, _ in items):
+        outs = []
+        for q, k, heads, lay, part, dq_out in items:
+            dq = ca_energy_loss_and_dq(q, k, heads, frames, lay, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                       com_loss_scale=com_loss_scale, loss_partial=part, **loss_options)
+            if dq_out is not None:
+                dq_out.copy_(dq)
+                dq = dq_out
+            outs.append(dq)
+        return outs
     opts = dict(use_ratio_based_loss=False, attn_sync_weight=0.0, boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1)
     opts.update(loss_options)
     n = len(items)
     A, B, Cq = (hip.CaProbsParams * n)(), (hip.CaSelectParams * n)(), (hip.CaDqParams * n)()
     keeps = []
-    for i, (q, k, heads, lay, part) in enumerate(items):
+    for i, (q, k, heads, lay, part, dq_out) in enumerate(items):
         if lay.ntok and int(lay.tok_ids_host.max()) >= ntext:  # the reference indexes attn[..., pos] and raises the same way
             raise IndexError(f"object token position {int(lay.tok_ids_host.max())} is out of bounds for {ntext} text tokens")
         a, b, c, keep = _ca_params(q, k, heads, frames, lay, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
-                                   com_loss_scale=com_loss_scale, loss_partial=part, want_dq=True, **opts)
+                                   com_loss_scale=com_loss_scale, loss_partial=part, want_dq=True, dq_out=dq_out, **opts)
         A[i], B[i], Cq[i] = a, b, c
         keeps.append(keep)
     st = torch.cuda.current_stream().cuda_stream
@@ -240,6 +252,52 @@ def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_p
     g0 = Geom(1, frames, latents.shape[3], latents.shape[4])
     grad = engine.input_gradient(tape, g0, scale=latent_scale)
     return loss, grad
+
+
+def guidance_loss_and_grad_many(engine: HipUNet3D, latents, t, text, bboxes_list, object_positions_list, guidance_attn_keys, *, loss_scale,
+                                fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0, com_loss_scale=0.0, latent_scale=1.0, **loss_options):
+    """`guidance_loss_and_grad` for V independent samples in ONE recorded forward / backward of batch V (throughput mode: the UNet levels whose
+    grids do not fill 256 CUs at batch 1 — most of a guidance pass — run at twice the rows).  latents (V,4,F,h,w); `text` a TextCache of the V
+    cond embeddings; one (bboxes, object_positions) layout per sample.  The energies stay per sample: every key's query rows and text keys are
+    sliced per sample, each sample's loss kernels see exactly what a batch-1 call hands them (own boxes, own token positions, own
+    grad_scale = loss_scale / (objects x keys)), and write dQ into their rows of one [V*F*P, C] matrix per key.
+    Returns ([V] list of loss tensors, grad (V,4,F,h,w) fp32)."""
+    V = latents.shape[0]
+    assert V == len(bboxes_list) == len(object_positions_list) == text.B
+    keys = [tuple(k) for k in guidance_attn_keys]
+    tape = Tape()
+    collect = {"keys": set(keys), "q": {}, "stop_after": _last_key_in_order(engine, keys)}
+    engine.forward(latents, t, text=text, tape=tape, collect=collect)
+    missing = [k for k in keys if k not in collect["q"]]
+    if missing:
+        raise KeyError(f"guidance keys not produced by this UNet: {missing}")
+    frames = latents.shape[2]
+    dq_full = {key: torch.empty_like(collect["q"][key][0]) for key in keys}
+    losses = []
+    for v in range(V):
+        bboxes, object_positions = bboxes_list[v], object_positions_list[v]
+        grad_scale = loss_scale / (len(bboxes) * len(keys))
+        ntok = sum(len(p) for p in object_positions)
+        sizes = [frames * collect["q"][key][2] * ntok for key in keys]
+        partial = torch.empty((sum(sizes),), dtype=torch.float32, device=latents.device)
+        layouts, items, off = {}, [], 0
+        for key, n in zip(keys, sizes):
+            q, k, heads, g = collect["q"][key]
+            rows = frames * g.HW
+            lay = layouts.get((g.H, g.W))
+            if lay is None:
+                lay = layouts[(g.H, g.W)] = GuidanceLayout(bboxes, object_positions, frames, g.H, g.W, fg_top_p, bg_top_p, latents.device)
+            items.append((q[v * rows:(v + 1) * rows], k[v * text.ntext:(v + 1) * text.ntext], heads, lay, partial[off:off + n],
+                          dq_full[key][v * rows:(v + 1) * rows]))
+            off += n
+        ca_energy_loss_and_dq_all_keys(items, frames, ntext=text.ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                       com_loss_scale=com_loss_scale, **loss_options)
+        losses.append(ops.reduce_sum(partial, grad_scale))
+    for key in keys:
+        tape.accumulate(collect["q"][key][0], dq_full[key])
+    tape.backward()
+    grad = engine.input_gradient(tape, Geom(V, frames, latents.shape[3], latents.shape[4]), scale=latent_scale)
+    return losses, grad
 
 
 def _key_order(engine):
@@ -336,3 +394,70 @@ def hip_latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes
     if return_saved_attn:
         return latents, loss, saved_attn_to_return
     return latents, loss
+
+
+def hip_latent_backward_guidance_many(scheduler, unet, text, index, bboxes_list, object_positions_list, t, latents_list, loss_list,
+                                      loss_scale=30, loss_threshold=0.2, max_iter=5, max_index_step=10, guidance_attn_keys=None, verbose=False,
+                                      **kwargs):
+    """`hip_latent_backward_guidance` for V samples that share the schedule and the guidance hyper-parameters (pipeline.sample_many): every
+    iteration runs the samples whose carried loss is still above the threshold through ONE recorded forward / backward
+    (`guidance_loss_and_grad_many`); a sample leaves the batch as soon as its own loop condition (models/pipelines.py:81) fails, exactly when
+    a batch-1 loop over it would have stopped.  `text`: TextCache of the V cond embeddings.  Returns ([latents_v], [loss_v])."""
+    engine = getattr(unet, "engine", unet)
+    for k, default in _UNSUPPORTED.items():
+        if k in kwargs and kwargs[k] != default:
+            raise NotImplementedError(f"guidance option {k}={kwargs[k]!r} is outside the hot path built here")
+    if guidance_attn_keys is None:
+        guidance_attn_keys = DEFAULT_GUIDANCE_ATTN_KEYS
+    loss_kw = {k: kwargs[k] for k in _LOSS_OPTIONS if k in kwargs}
+    V = len(latents_list)
+    latents_list, loss_list = list(latents_list), list(loss_list)
+    if isinstance(max_iter, list):
+        max_iter = max_iter[index] if index < len(max_iter) else 0
+    vals = []
+    for loss in loss_list:
+        host = getattr(loss, "_host_copy", None)
+        if host is not None:
+            host[1].synchronize()
+            vals.append(float(host[0]))
+        else:
+            vals.append(float(loss))
+    if index >= max_index_step:
+        return latents_list, loss_list
+    for v in range(V):  # no boxes = no guidance (see hip_latent_backward_guidance)
+        if len(bboxes_list[v]) == 0:
+            loss_list[v], vals[v] = torch.zeros((), device=latents_list[v].device), 0.0
+    if hasattr(scheduler, "alphas_cumprod"):
+        scale = float((1 - scheduler.alphas_cumprod[int(t)]) ** 0.5)
+    else:
+        warnings.warn("No scaling in guidance is performed")
+        scale = 1.0
+    iteration = 0
+    while iteration < max_iter:
+        active = [v for v in range(V) if vals[v] / loss_scale > loss_threshold and len(bboxes_list[v])]
+        if not active:
+            break
+        lat = torch.cat([latents_list[v] for v in active]).to(torch.float32).contiguous()
+        lat_in = scheduler.scale_model_input(lat, t) if hasattr(scheduler, "scale_model_input") else lat
+        sub_text = text if len(active) == V else engine.text_subset(text, active)
+        losses, grad = guidance_loss_and_grad_many(engine, lat_in, t, sub_text, [bboxes_list[v] for v in active],
+                                                   [object_positions_list[v] for v in active], guidance_attn_keys, loss_scale=loss_scale, **loss_kw)
+        iteration += 1
+        more = iteration < max_iter or verbose
+        for i, v in enumerate(active):
+            latents_list[v] = ops.axpy_(lat[i:i + 1].contiguous().clone(), grad[i:i + 1].contiguous(), scale)
+            loss_list[v] = losses[i]
+            if not more:  # last iteration: hand the value to the next step's entry check through pinned memory (no stall here)
+                pinned = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                pinned.copy_(losses[i].reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                losses[i]._host_copy = (pinned, ev)
+        if more:
+            for i, v in enumerate(active):
+                vals[v] = float(losses[i].item())
+                if math.isnan(vals[v]):
+                    print("**Loss is NaN**")
+                if verbose:
+                    print(f"sample {v}, time index {index}, loss: {vals[v] / loss_scale:.3f}, loss threshold: {loss_threshold:.3f}, iteration: {iteration}")
+    return latents_list, loss_list

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..guidance import hip_latent_backward_guidance
+from ..guidance import hip_latent_backward_guidance, hip_latent_backward_guidance_many
 from ..sampler import DPMSolverPP2MSchedule
 
 
@@ -202,11 +202,27 @@ class TextToVideoSDPipeline:
         num_grounding_steps = int(gligen_scheduled_sampling_beta * len(timesteps))
         self.enable_fuser(True)
         backward_guidance = custom_latent_backward_guidance if custom_latent_backward_guidance else hip_latent_backward_guidance
+        # V > 1 with the stock guidance function and the same guidance hyper-parameters for every sample (what run_many builds): the V guidance
+        # passes of a step are ONE recorded forward / backward of batch V (guidance.hip_latent_backward_guidance_many) — per-sample layouts,
+        # losses, thresholds and iteration counts as in the one-by-one loop.  Anything else keeps the one-by-one loop below.
+        shared_hp = None
+        if V > 1 and backward_guidance is hip_latent_backward_guidance and not return_guidance_saved_attn and guidance_type == "main" \
+                and all(st["bg_kwargs"] is not None and st["guidance_callback"] is None for st in states):
+            hps = [{k: v for k, v in st["bg_kwargs"].items() if k not in ("bboxes", "object_positions")} for st in states]
+            if all(h == hps[0] for h in hps[1:]):
+                shared_hp = hps[0]
+                text_cond_all = engine.encode_text(torch.cat([st["prompt_embeds"][1:2] for st in states]))
         for i, t in enumerate(timesteps):
             t = int(t)
             if i == num_grounding_steps:
                 self.enable_fuser(False)
-            for st in states:
+            if shared_hp is not None:
+                lats, losses = hip_latent_backward_guidance_many(self.scheduler, self.unet, text_cond_all, i, [st["bg_kwargs"]["bboxes"] for st in states],
+                                                                 [st["bg_kwargs"]["object_positions"] for st in states], t,
+                                                                 [st["latents"] for st in states], [st["loss_attn"] for st in states], **shared_hp)
+                for st, lat, ls in zip(states, lats, losses):
+                    st["latents"], st["loss_attn"] = lat, ls
+            for st in (states if shared_hp is None else ()):
                 assert st["latents"].shape[1] == 4, f"latent channel mismatch: {st['latents'].shape}"
                 if st["bg_kwargs"] is not None:
                     if guidance_type != "main":
