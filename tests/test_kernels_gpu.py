@@ -526,10 +526,21 @@ def test_gemm_layernorm_fold_geglu(variant):
 
 def test_gemm_layernorm_fold_rejects_kernels_without_it():
     x, W = bf(rnd(256, 320, seed=1)), bf(rnd(320, 320, seed=2, scale=0.05))
-    mr, cs = ops.layernorm_stats(x), W.float().sum(1).contiguous()
+    mr, cs, b = ops.layernorm_stats(x), W.float().sum(1).contiguous(), rnd(320, seed=3)
     for v in (1, 10, 5, 11):  # register-staged / builtin-DMA kernels have no folded epilogue: an error, not a silently un-normalised product
         with pytest.raises(RuntimeError, match="LayerNorm-folded"):
-            ops.gemm(x, W, ln_stats=mr, ln_colsum=cs, variant=v)
+            ops.gemm(x, W, bias=b, ln_stats=mr, ln_colsum=cs, variant=v)
+    # the folded epilogue always reads the bias row (b + W beta) from its LDS strip: a product without one is refused, at both levels
+    with pytest.raises(AssertionError, match="bias"):
+        ops.gemm(x, W, ln_stats=mr, ln_colsum=cs, variant=111)
+    from lvd_amd import hip
+    p = hip.GemmParams()
+    out = torch.empty(256, 320, dtype=torch.bfloat16, device=DEV)
+    p.a1, p.w, p.out, p.M, p.N, p.K, p.lda1, p.c1, p.cin, p.ldc, p.alpha = x.data_ptr(), W.data_ptr(), out.data_ptr(), 256, 320, 320, 320, 320, 320, 320, 1.0
+    p.ln_mean_rstd, p.ln_colsum, p.variant = mr.data_ptr(), cs.data_ptr(), 111
+    import ctypes
+    assert hip.lib().lvdhip_gemm(ctypes.byref(p), torch.cuda.current_stream().cuda_stream) != 0
+    assert "bias" in hip.lib().lvdhip_last_error().decode()
 
 
 @pytest.mark.parametrize("variant", [1, 5, 9, 10, 11, 14, 17, 31, 37, 41, 45, 47, 105, 106, 109, 111, 117, 120, 125, 131, 137, 161, 211, 225, 231])
