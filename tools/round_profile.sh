@@ -23,12 +23,19 @@ timeout 300 python tools/quant_probe.py > $O/${T}_short_k_quantisation.txt 2>&1
 timeout 300 python tools/host_profile.py > $O/${T}_host_profile.txt 2>&1
 # GroupNorm per shape by kernel duration: the single-launch slab-in-registers kernel against statistics + apply
 bash tools/gn_probe.sh > /dev/null 2>&1; cp $O/gn_probe.txt $O/${T}_groupnorm_kernels.txt
+# round 5: the per-shape roofline model of the plain GEMMs, the persistent walker against the one-shot kernels, its phase trace (needs
+# tools/build_ablations.sh on the build host), spatial attention v2 / v3
+timeout 300 python tools/gemm_roofline_model.py > $O/${T}_gemm_roofline_model.txt 2> $O/${T}_gemm_roofline_model.err
+timeout 300 python tools/stream_bench.py --no-check > $O/${T}_stream_walker.txt 2>&1
+[ -f build/abl/liblvdhip_strace.so ] && LVD_LIB=build/abl/liblvdhip_strace.so timeout 200 python tools/stream_trace.py > $O/${T}_stream_trace.txt 2>&1
+for v in 2 3; do echo "== LVD_ATTN_VARIANT=$v"; LVD_ATTN_VARIANT=$v timeout 200 python tools/attn_bench.py 2>&1 | grep -E "spatial" | cut -c1-52; done > $O/${T}_attention_fwd.txt
 timeout 400 python bench.py --videos-per-gpu 2 --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_2videos.json 2> $O/${T}_bench_2videos.err
+timeout 400 python bench.py --videos-per-gpu 2 --guidance-one-by-one --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_2videos_one_by_one.json 2> $O/${T}_bench_2videos_one_by_one.err
 timeout 400 python bench.py --gligen --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_gligen.json 2> $O/${T}_bench_gligen.err
 LVD_CFG_SHARED_PREFIX=0 timeout 400 python bench.py --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_no_shared_prefix.json 2> $O/${T}_bench_no_shared_prefix.err
 python - <<'PY'
 import json
-for f in ("r05_bench", "r05_bench_under_rocprof", "r05_bench_2videos", "r05_bench_gligen", "r05_bench_no_shared_prefix"):
+for f in ("r05_bench", "r05_bench_under_rocprof", "r05_bench_2videos", "r05_bench_2videos_one_by_one", "r05_bench_gligen", "r05_bench_no_shared_prefix"):
     try:
         j = json.load(open(f"gpurun_out/{f}.json"))
         print(f, j["value"], j["ms_per_step"], j.get("unguided_ms_per_step"), j.get("step_mfma_frac"), {k: (v["ms_per_step"], v["frac"]) for k, v in j["roofline"]["all_gemm"].items()})
