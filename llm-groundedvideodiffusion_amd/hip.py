@@ -190,7 +190,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 103
+ABI_VERSION = 104
 CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 

@@ -8,7 +8,7 @@ import sys
 
 CLASSES = [
     ("tap GEMM, LDS-resident im2col (conv_halo.hip: 3x3 conv, temporal conv, their split-K reduce)", ("tap_gemm_kernel", "tap_reduce_kernel")),
-    ("GEMM family (gemm.hip, gemm_ring.hip, split-K reduce)", ("gemm_kernel", "gemm_ring_kernel", "splitk_reduce")),
+    ("GEMM family (gemm.hip, gemm_ring.hip, gemm_stream.hip, split-K reduce)", ("gemm_kernel", "gemm_ring_kernel", "gemm_stream_kernel", "splitk_reduce")),
     ("GroupNorm", ("gn_",)),
     ("attention fwd/bwd", ("attn_",)),
     ("LayerNorm", ("ln_",)),
