@@ -168,7 +168,7 @@ def _tune_gemm(p, key, out):
 
 def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sample=0, res=None, out=None,
          mode=A_PLAIN, conv: Optional[ConvGeom] = None, frames=0, hw=0, cin=None, act=ACT_NONE, out_fp32=False,
-         alpha=1.0, accumulate=False, m=None, variant=0, m_begin=0, ln_stats=None, ln_colsum=None):
+         alpha=1.0, accumulate=False, m=None, variant=0, m_begin=0, ln_stats=None, ln_colsum=None, ksplit=0):
     """OUT[M,N] = epi(Aload · W^T).  `w` is [N,K] bf16.  Returns `out`.  `m_begin` > 0 produces rows [m_begin, M) only.
     ln_stats ([M,2] fp32 mean/rstd from layernorm_stats) + ln_colsum ([N] fp32): LayerNorm(a1) · W^T with the norm folded into the product —
     `w` must then be gamma (.) W and `bias` b + W beta (engine._pack builds them)."""
@@ -228,6 +228,7 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
         if variant == 0 and not torch.cuda.is_current_stream_capturing():  # a capture replays what a warm-up run has tuned
             variant = _tune_gemm(p, key, out)
     p.variant = variant
+    p.ksplit = ksplit  # 0: the library's plan (K-split variants only)
     _launch_gemm(p)
     return out
 
