@@ -206,8 +206,24 @@ SMALL = {small!r}
 _common.configure(state_dict=synthetic_state_dict(UNetConfig(**SMALL), seed=0), unet_config=dict(SMALL), tokenizer=FakeClipTokenizer(),
                   text_encoder=FakeTextEncoder(64), vae=fake_vae_decode)
 n = generate.main(sys.argv[1:])
-print("GENERATED", n, flush=True)
+# one file per rank: ranks of one torch.distributed.run share a stdout pipe and their writes may interleave mid-line
+import json, os
+rank = int(os.environ.get("RANK", "0"))
+with open(os.path.join(os.environ["LVD_TEST_TALLY_DIR"], f"generated_rank{{rank}}.json"), "w") as fh:
+    json.dump({{"rank": rank, "generated": n}}, fh)
 '''
+
+
+def _tally(d):
+    """{rank: videos generated} from the per-rank files the driver script leaves in `d` (then removed, so that the next run starts clean)."""
+    out = {}
+    for name in sorted(os.listdir(d)):
+        if name.startswith("generated_rank"):
+            with open(os.path.join(d, name)) as fh:
+                rec = json.load(fh)
+            out[rec["rank"]] = rec["generated"]
+            os.remove(os.path.join(d, name))
+    return out
 
 
 def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
@@ -237,14 +253,16 @@ def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
                 "--repeats", "1", "--cache-dir", str(cache_dir), "--img-root", str(tmp_path / out),
                 "--gemm_autotune_table", str(table)] + (["--force_run_ind", "0"] if pin_run else [])
 
-    env = dict(os.environ, LVD_DIST_BACKEND="gloo", PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    tally_dir = tmp_path / "tally"
+    tally_dir.mkdir()
+    env = dict(os.environ, LVD_DIST_BACKEND="gloo", PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""), LVD_TEST_TALLY_DIR=str(tally_dir))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     one = subprocess.run([sys.executable, str(driver)] + argv("one"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
-    assert one.returncode == 0 and "GENERATED 4" in one.stdout, one.stdout[-2000:] + one.stderr[-2000:]
+    assert one.returncode == 0 and _tally(tally_dir) == {0: 4}, one.stdout[-2000:] + one.stderr[-2000:]
     assert table.exists()
     pinned = subprocess.run([sys.executable, str(driver)] + argv("pinned"), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
-    assert pinned.returncode == 0 and "GENERATED 4" in pinned.stdout, pinned.stdout[-2000:] + pinned.stderr[-2000:]
+    assert pinned.returncode == 0 and _tally(tally_dir) == {0: 4}, pinned.stdout[-2000:] + pinned.stderr[-2000:]
     import socket
     with socket.socket() as sk:  # a port nothing else on this box holds
         sk.bind(("127.0.0.1", 0))
@@ -252,7 +270,7 @@ def test_generate_two_ranks_reproduce_the_single_process_run(tmp_path):
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), str(driver)] + argv("two", pin_run=False), env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
-    assert two.stdout.count("GENERATED 2") == 2, two.stdout[-2000:]  # two prompts per rank
+    assert _tally(tally_dir) == {0: 2, 1: 2}, two.stdout[-2000:] + two.stderr[-2000:]  # two prompts per rank
     root = "imgs_shardtest_templatev0.1_lvd_zeroscope/run0"
     # no --force_run_ind in the sharded run: rank 0 picks the run directory and broadcasts it, so there is exactly one
     assert sorted(os.listdir(tmp_path / "two" / "imgs_shardtest_templatev0.1_lvd_zeroscope")) == ["run0"]
