@@ -303,6 +303,32 @@ typedef struct {
 } lvd_ca_probs_params;
 int lvdhip_ca_probs(const lvd_ca_probs_params* p, void* stream);
 
+/* The whole probability map softmax(scale * Q K^T) over ALL text positions, as AttnProcessor's slow path materialises and saves it
+ * (models/attention_processor.py:515-552, Attention.get_attention_scores :222-258; stored at :553-586 as (batch, heads, HW, tokens)).
+ * Not used by the guidance loss (which keeps only the object-token columns); used by the plug-in's `return_attntion_probs` /
+ * `save_attn_to_dict` / `attn_process_fn` branch and by `return_saved_attn`.  Sample s reads the text keys of block s / samples_per_key
+ * (1: every sample has its own keys, as the processor sees them; F: the F frames of a video share their prompt's keys). */
+typedef struct {
+  const lvd_bf16* q; int32_t ldq;       /* [samples*P, heads*64] */
+  const lvd_bf16* k; int32_t ldk;       /* [(samples / samples_per_key) * ntext, heads*64] */
+  int32_t samples, heads, P, ntext;     /* ntext <= 96 */
+  int32_t samples_per_key;
+  float scale;
+  float* probs;                         /* out [samples, heads, P, ntext] fp32 */
+} lvd_ca_probs_full_params;
+int lvdhip_ca_probs_full(const lvd_ca_probs_full_params* p, void* stream);
+
+/* hidden = bmm(attention_probs, value) of the same slow path (models/attention_processor.py:549) for probabilities that come from memory —
+ * i.e. after the caller's `attn_process_fn` rewrote them (:537-548).  out[(s*P + q), h*64 + d] = sum_t probs[s,h,q,t] * v[key block of s][t, h*64 + d]. */
+typedef struct {
+  const float* probs;                   /* [samples, heads, P, ntext] fp32 */
+  const lvd_bf16* v; int32_t ldv;       /* [(samples / samples_per_key) * ntext, heads*64]; 16-byte aligned rows */
+  int32_t samples, heads, P, ntext;     /* ntext <= 256 */
+  int32_t samples_per_key;
+  lvd_bf16* out; int32_t ldo;           /* [samples*P, heads*64]; 16-byte aligned rows */
+} lvd_ca_apply_probs_params;
+int lvdhip_ca_apply_probs(const lvd_ca_apply_probs_params* p, void* stream);
+
 typedef struct {
   const float* probs;                   /* [frames, heads, ntok, P] */
   float* dprobs;                        /* out, same shape: d(loss)/d(probs), already scaled by grad_scale */
@@ -317,8 +343,10 @@ typedef struct {
   float* loss_partial;                  /* out [frames*heads*ntok]: per-(frame,head,token) loss terms, un-scaled */
   float* com_ws;                        /* workspace [frames, heads, ntok, 4] = (sum, com_y, com_x, -) */
   /* optional terms of add_ca_loss_per_attn_map_to_loss (all off = the max-based top-k energy of the entry points' defaults) */
-  int32_t use_ratio_loss;               /* utils/guidance.py:312-323: (1 - sum(A*mask)/(sum(A)+eps))^2, mean over heads, instead of top-k */
-  float ratio_eps;                      /* 1e-2 in the reference */
+  int32_t use_ratio_loss;               /* energy form: 0 = max-based top-k (default, :346-353); 1 = ratio-based (utils/guidance.py:312-323:
+                                           (1 - sum(A*mask)/(sum(A)+eps))^2, mean over heads); 2 = CE / NLL over the same top-k sets (:363-399:
+                                           A clamped to [eps, 1-eps], fg = mean(-log topk), bg = -log(1 - mean topk), summed over heads) */
+  float ratio_eps;                      /* `eps` of the ratio and CE forms; 1e-2 in the reference */
   float attn_sync_weight;               /* :401-430: w * mean over the NEXT frame's box of (A_f - A_f+1)^2, summed over heads */
   float boxdiff_loss_scale;             /* :433-465: BoxDiff corner constraint on the row / column maxima */
   int32_t boxdiff_normed;               /* 1: mean over (heads, W|H); 0: sum */

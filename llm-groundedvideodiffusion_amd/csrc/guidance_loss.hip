@@ -182,6 +182,112 @@ LVD_DEV void ca_probs_body3(const lvd_ca_probs_params& p, const int bx, const in
   }
 }
 
+// ------------------------------------------------------------------------------------ 1b. full maps (AttnProcessor's saved-probabilities branch)
+// The reference's slow path (models/attention_processor.py:515-552 -> Attention.get_attention_scores :222-258) materialises
+// softmax(scale * Q K^T) over ALL text positions and stores it as (batch, heads, HW, tokens).  The guidance loss above never needs that
+// tensor; visualisation, `return_attntion_probs` and `attn_process_fn` callers do.  Same staging and MFMA tiles as ca_probs_body3 (prompts of
+// up to 96 positions), one 32-query tile per wave; a lane ends up with its query's scores of keys kt*32 + 8 j + 4 hi + (0..3), normalises
+// them in registers and writes them as runs of four.  out[((s * heads + h) * P + q) * ntext + key], fp32.
+__global__ __launch_bounds__(256) void ca_probs_full_kernel(const lvd_ca_probs_full_params p) {
+  __shared__ uint32_t k_lds[96 * KROW];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int nqt = (p.P + 31) >> 5;
+  const int h = blockIdx.x % p.heads;
+  const int tile = (blockIdx.x / p.heads) * 4 + (threadIdx.x >> 6);
+  // the four tiles of a workgroup must share their keys: workgroups never straddle samples (tiles of a sample are padded to a multiple of 4)
+  const int tiles_per_sample = (nqt + 3) & ~3;
+  const int s = tile / tiles_per_sample, qt = tile - s * tiles_per_sample;
+  const bool live = qt < nqt;
+  const int qi = qt * 32 + l31;
+  const int qic = min(qi, p.P - 1);
+  const lvd_bf16* qp = p.q + ((long)s * p.P + qic) * p.ldq + h * 64 + hi * 8;
+  uint4 qraw[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qraw[ks] = ldg16(qp + ks * 16);
+  const lvd_bf16* kb = p.k + (long)(s / p.samples_per_key) * p.ntext * p.ldk;
+  kstage_store(k_lds, kstage_load(kb, p.ldk, p.ntext, h));
+  __syncthreads();
+  if (!live) return;
+  const float sc = p.scale * 1.4426950408889634f;
+  float v[3][16], m = -1e30f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kstage_frag(k_lds, kt, ks, l31, hi), as_bf16x8(qraw[ks]), st, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      v[kt][e] = kidx < p.ntext ? st[e] * sc : -1e30f;
+      m = fmaxf(m, v[kt][e]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float lsum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { v[kt][e] = fast_exp2(v[kt][e] - m); lsum += v[kt][e]; }
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = 1.f / lsum;
+  if (qi >= p.P) return;
+  float* o = p.probs + (((long)s * p.heads + h) * p.P + qi) * p.ntext;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      if (kidx < p.ntext) o[kidx] = v[kt][e] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------ 1c. (processed) probabilities x V
+// The other half of the reference's slow path: hidden = bmm(attention_probs, value) (models/attention_processor.py:549), where the
+// probabilities may have been rewritten by the caller's `attn_process_fn` (:537-548) — so they come from memory, fp32, not from the
+// fused attention kernel.  64 query rows per workgroup: the rows' probabilities and the head's V rows are staged in LDS (coalesced
+// loads), each thread owns (row, 16 channels).  HBM-bound by the fp32 map (ntext * 4 bytes per (row, head) against 128 bytes of output).
+__global__ __launch_bounds__(256) void ca_apply_probs_kernel(const lvd_ca_apply_probs_params p) {
+  extern __shared__ float apply_lds[];
+  float* pl = apply_lds;                    // [64][ntext] probabilities of the tile, row pitch ntext | 1 (odd: conflict-free columns)
+  const int pitch = p.ntext | 1;
+  float* vl = apply_lds + 64 * pitch;       // [ntext][64] V of this (sample, head)
+  const int sh = blockIdx.y, s = sh / p.heads, h = sh - s * p.heads;
+  const int row0 = blockIdx.x * 64, rows = min(64, p.P - row0);
+  const float* src = p.probs + ((long)sh * p.P + row0) * p.ntext;
+  for (int i = threadIdx.x; i < rows * p.ntext; i += 256) {
+    const int r = i / p.ntext, t = i - r * p.ntext;
+    pl[r * pitch + t] = src[i];
+  }
+  const lvd_bf16* vb = p.v + (long)(s / p.samples_per_key) * p.ntext * p.ldv + h * 64;
+  for (int i = threadIdx.x; i < p.ntext * 8; i += 256) {
+    const int t = i >> 3, c = (i & 7) * 8;
+    const uint4 raw = ldg16(vb + (long)t * p.ldv + c);
+    float* d = vl + t * 64 + c;
+    d[0] = bflo(raw.x); d[1] = bfhi(raw.x); d[2] = bflo(raw.y); d[3] = bfhi(raw.y);
+    d[4] = bflo(raw.z); d[5] = bfhi(raw.z); d[6] = bflo(raw.w); d[7] = bfhi(raw.w);
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+  if (r >= rows) return;
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int t = 0; t < p.ntext; ++t) {
+    const float a = pl[r * pitch + t];
+    const float4* vv = reinterpret_cast<const float4*>(vl + t * 64 + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 x = vv[e];
+      acc[4 * e] += a * x.x; acc[4 * e + 1] += a * x.y; acc[4 * e + 2] += a * x.z; acc[4 * e + 3] += a * x.w;
+    }
+  }
+  lvd_bf16* o = p.out + ((long)s * p.P + row0 + r) * p.ldo + h * 64 + c0;
+  stg16(o, make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])));
+  stg16(o + 8, make_uint4(pack2bf(acc[8], acc[9]), pack2bf(acc[10], acc[11]), pack2bf(acc[12], acc[13]), pack2bf(acc[14], acc[15])));
+}
+
 // ------------------------------------------------------------------------------------ 2a. centre of mass
 // grid frames*heads*ntok, block 256: com_ws[.,4] = (sum A, com_y, com_x, 0)
 LVD_DEV void ca_com_body(const lvd_ca_select_params& p, const int b) {
@@ -334,7 +440,8 @@ LVD_DEV void ca_select_wave(const lvd_ca_select_params& p, const int b, unsigned
   }
 
   unsigned long long thr_fg = ~0ull, thr_bg = ~0ull;  // "nothing selected"
-  const bool ratio = p.use_ratio_loss != 0;
+  const bool ratio = p.use_ratio_loss == 1;
+  const bool ce = p.use_ratio_loss == 2;  // NLL form of the top-k energy (utils/guidance.py:363-399)
   if (!ratio) {
     unsigned long long thr[2];
     radix_select2_wave<E>(a, cls, p.P, lane, kbg, kfg, p.P - nmask > 0, nmask > 0, hist, thr);
@@ -410,7 +517,21 @@ LVD_DEV void ca_select_wave(const lvd_ca_select_params& p, const int b, unsigned
   }
 
   float sfg = 0.f, sbg = 0.f, ssync = 0.f;
-  const float gfg = -p.fg_weight / (float)kfg, gbg = p.bg_weight / (float)kbg;
+  const float gfg = -p.fg_weight / (float)kfg;
+  float gbg = p.bg_weight / (float)kbg;
+  // CE: the map is clamped to [eps, 1 - eps] first (gradient 1 inside the interval, 0 outside); selecting on the raw values picks the same
+  // top-k sums (the clamp is monotone; entries it ties carry no gradient).  fg = mean over the set of -log(a), bg = -log(1 - mean of the
+  // set): the background gradient needs that mean before any dA is written, hence the extra sweep.
+  const float ce_lo = p.ratio_eps, ce_hi = 1.f - p.ratio_eps;
+  if (ce) {
+    float pre = 0.f;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      if (j * 64 >= p.P) break;  // wave-uniform
+      if (cls[j] == 0 && select_key(a[j], j * 64 + lane) >= thr_bg) pre += fminf(fmaxf(a[j], ce_lo), ce_hi);
+    }
+    gbg = p.bg_weight / ((1.f - wave_total(pre) / (float)kbg) * (float)kbg);
+  }
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int i = j * 64 + lane;
@@ -421,6 +542,14 @@ LVD_DEV void ca_select_wave(const lvd_ca_select_params& p, const int b, unsigned
     float g = 0.f;
     if (ratio) {
       g += cls[j] ? r_in : r_out;
+    } else if (ce) {
+      const float ac = fminf(fmaxf(av, ce_lo), ce_hi);
+      const float inside = (av >= ce_lo && av <= ce_hi) ? 1.f : 0.f;
+      if (cls[j]) {
+        if (key >= thr_fg) { sfg -= logf(ac); g += inside * gfg / ac; }
+      } else {
+        if (key >= thr_bg) { sbg += ac; g += inside * gbg; }
+      }
     } else if (cls[j]) {
       if (key >= thr_fg) { sfg += av; g += gfg; }
     } else {
@@ -438,6 +567,8 @@ LVD_DEV void ca_select_wave(const lvd_ca_select_params& p, const int b, unsigned
   }
   const float tf = wave_total(sfg), tb = wave_total(sbg), tsync = wave_total(ssync);
   float loss = ratio ? ratio_loss : p.fg_weight * (1.f - tf / (float)kfg) + p.bg_weight * (tb / (float)kbg);
+  // CE with an empty box: the reference's top-1 of an all-zero masked map is clamped to eps (:381-386) — a constant -log(eps)
+  if (ce) loss = p.fg_weight * (nmask > 0 ? tf / (float)kfg : -logf(ce_lo)) - p.bg_weight * logf(1.f - tb / (float)kbg);
   loss += com_loss + snext * tsync;
 
   // BoxDiff corner constraint (:240-287, 433-465): |max over rows/columns of A - max of the mask| on the corner columns/rows;
@@ -884,6 +1015,35 @@ extern "C" int lvdhip_ca_dq_multi(const lvd_ca_dq_params* keys, int32_t nkeys, v
   else if (nt <= 4) launch_dq<4>(tab, blocks, brief, s);
   else if (nt <= 8) launch_dq<8>(tab, blocks, brief, s);
   else launch_dq<MAXTOK>(tab, blocks, brief, s);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_probs_full(const lvd_ca_probs_full_params* p, void* stream) {
+  LVD_CHECK(p && p->q && p->k && p->probs, "ca_probs_full: null pointer");
+  LVD_CHECK(p->samples > 0 && p->heads > 0 && p->P > 0 && p->samples_per_key > 0, "ca_probs_full: empty problem");
+  LVD_CHECK(p->ntext >= 1 && p->ntext <= 96, "ca_probs_full: %d text positions (1..96 supported; CLIP has 77)", p->ntext);
+  LVD_CHECK(p->ldq % 8 == 0 && p->ldk % 8 == 0, "ca_probs_full: leading dims");
+  const int tiles_per_sample = (((p->P + 31) / 32) + 3) & ~3;
+  const long blocks = (long)p->samples * (tiles_per_sample / 4) * p->heads;
+  LVD_CHECK(blocks < (1l << 31), "ca_probs_full: grid too large");
+  hipLaunchKernelGGL(ca_probs_full_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  LVD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvdhip_ca_apply_probs(const lvd_ca_apply_probs_params* p, void* stream) {
+  LVD_CHECK(p && p->probs && p->v && p->out, "ca_apply_probs: null pointer");
+  LVD_CHECK(p->samples > 0 && p->heads > 0 && p->P > 0 && p->samples_per_key > 0, "ca_apply_probs: empty problem");
+  LVD_CHECK(p->ntext >= 1 && p->ntext <= 256, "ca_apply_probs: %d text positions (1..256 supported)", p->ntext);
+  LVD_CHECK(p->ldv % 8 == 0 && p->ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(p->out) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->v) & 15) == 0,
+            "ca_apply_probs: v / out rows must be 16-byte aligned");
+  LVD_CHECK((long)p->samples * p->heads < 65536, "ca_apply_probs: samples x heads = %ld exceeds the grid", (long)p->samples * p->heads);
+  const size_t smem = sizeof(float) * ((size_t)64 * (p->ntext | 1) + (size_t)p->ntext * 64);
+  if (smem > 48 * 1024)
+    LVD_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ca_apply_probs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess,
+              "ca_apply_probs: %zu bytes of LDS refused", smem);
+  hipLaunchKernelGGL(ca_apply_probs_kernel, dim3((p->P + 63) / 64, p->samples * p->heads), dim3(256), smem, (hipStream_t)stream, *p);
   LVD_LAUNCH_CHECK();
   return 0;
 }

@@ -27,11 +27,21 @@ from .engine import HipUNet3D, Tape, Geom
 DEFAULT_GUIDANCE_ATTN_KEYS = [("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0)]  # models/pipelines.py:13-18
 
 # loss options of utils/guidance.py:160-526 that are NOT built (none is reachable from generate.py's command line): they raise
-_UNSUPPORTED = dict(use_ce_based_loss=False, exclude_bg_heads=False, smooth_attn=False, attn_renorm=False, upsample_scale=1,
-                    use_max_based_loss=True)
+_UNSUPPORTED = dict(exclude_bg_heads=False, smooth_attn=False, attn_renorm=False, upsample_scale=1)
 # optional terms that ARE built into the fused loss kernel (generate.py:78-106, generation/lvd.py:85-106 forward them)
 _LOSS_OPTIONS = ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "com_loss_scale", "use_ratio_based_loss", "attn_sync_weight",
-                 "boxdiff_loss_scale", "boxdiff_normed", "boxdiff_L")
+                 "boxdiff_loss_scale", "boxdiff_normed", "boxdiff_L", "use_max_based_loss", "use_ce_based_loss")
+
+
+def _energy_form(use_ratio_based_loss, use_max_based_loss, use_ce_based_loss):
+    """The if / elif chain of utils/guidance.py:312,346,363,398 -> lvd_ca_select_params.use_ratio_loss (0 max, 1 ratio, 2 CE)."""
+    if use_ratio_based_loss:
+        return 1
+    if use_max_based_loss:
+        return 0
+    if use_ce_based_loss:
+        return 2
+    raise ValueError("Unknown loss: no loss selected")
 
 
 def scale_proportion(box, H, W):
@@ -45,6 +55,42 @@ def scale_proportion(box, H, W):
 def _topk_count(n, p):
     # (mask.sum() * top_p).long().clamp_(min=1) with a float32 mask sum (utils/guidance.py:328-337)
     return max(1, int(np.float32(n) * np.float32(p)))
+
+
+def ca_probability_maps(q, k, *, samples, heads, positions, ntext, samples_per_key=1, scale=0.125):
+    """softmax(scale * Q K^T) over all text positions as the reference's slow path materialises and saves it
+    (models/attention_processor.py:515-552 -> :553-586): q [samples*positions, heads*64] bf16, k [(samples / samples_per_key) * ntext,
+    heads*64] bf16 -> (samples, heads, positions, ntext) fp32, one launch of `lvdhip_ca_probs_full`."""
+    ops._chk_bf16(q, k)
+    if q.shape[0] != samples * positions or q.shape[1] != heads * 64 or k.shape[1] != heads * 64 or samples % samples_per_key \
+            or k.shape[0] != (samples // samples_per_key) * ntext:
+        raise ValueError(f"ca_probability_maps: q {tuple(q.shape)} / k {tuple(k.shape)} do not match samples={samples}, heads={heads}, "
+                         f"positions={positions}, ntext={ntext}, samples_per_key={samples_per_key}")
+    probs = torch.empty((samples, heads, positions, ntext), dtype=torch.float32, device=q.device)
+    a = hip.CaProbsFullParams(q=q.data_ptr(), ldq=q.stride(0), k=k.data_ptr(), ldk=k.stride(0), samples=samples, heads=heads, P=positions,
+                              ntext=ntext, samples_per_key=samples_per_key, scale=float(scale), probs=probs.data_ptr())
+    ops.use_device(q.device)
+    hip.check(hip.lib().lvdhip_ca_probs_full(C.byref(a), torch.cuda.current_stream().cuda_stream), "ca_probs_full")
+    return probs
+
+
+def ca_apply_probabilities(probs, v, *, samples, heads, positions, ntext, samples_per_key=1, out=None):
+    """bmm(attention_probs, value) of the slow path (models/attention_processor.py:549) for probabilities held in memory (after an
+    `attn_process_fn`): probs (samples, heads, positions, ntext) fp32, v [(samples / samples_per_key) * ntext, heads*64] bf16 ->
+    [samples*positions, heads*64] bf16 (`lvdhip_ca_apply_probs`)."""
+    ops._chk_bf16(v)
+    probs = probs.reshape(samples, heads, positions, ntext)
+    if probs.dtype != torch.float32 or not probs.is_contiguous():
+        probs = probs.float().contiguous()
+    if v.shape[1] != heads * 64 or samples % samples_per_key or v.shape[0] != (samples // samples_per_key) * ntext or probs.device != v.device:
+        raise ValueError(f"ca_apply_probabilities: probs {tuple(probs.shape)} / v {tuple(v.shape)} do not match samples_per_key={samples_per_key}")
+    if out is None:
+        out = torch.empty((samples * positions, heads * 64), dtype=torch.bfloat16, device=v.device)
+    a = hip.CaApplyProbsParams(probs=probs.data_ptr(), v=v.data_ptr(), ldv=v.stride(0), samples=samples, heads=heads, P=positions, ntext=ntext,
+                               samples_per_key=samples_per_key, out=out.data_ptr(), ldo=out.stride(0))
+    ops.use_device(v.device)
+    hip.check(hip.lib().lvdhip_ca_apply_probs(C.byref(a), torch.cuda.current_stream().cuda_stream), "ca_apply_probs")
+    return out
 
 
 class GuidanceLayout:
@@ -85,7 +131,7 @@ MAX_TOKENS_PER_LAUNCH = 16  # csrc/guidance_loss.hip MAXTOK: object-token column
 
 def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext, grad_scale, fg_weight, bg_weight,
                           com_loss_scale, loss_partial, want_dq=True, use_ratio_based_loss=False, attn_sync_weight=0.0,
-                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, _acc=None):
+                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, use_max_based_loss=True, use_ce_based_loss=False, _acc=None):
     """One guidance key: q [frames*P, heads*64] bf16, k [ntext, heads*64] bf16 (strided ok).
 
     Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ.  Layouts with
@@ -106,13 +152,13 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
                                        com_loss_scale=com_loss_scale, loss_partial=loss_partial[off:off + n], want_dq=want_dq,
                                        use_ratio_based_loss=use_ratio_based_loss, attn_sync_weight=attn_sync_weight,
                                        boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed, boxdiff_L=boxdiff_L,
-                                       _acc=(acc32, mode))
+                                       use_max_based_loss=use_max_based_loss, use_ce_based_loss=use_ce_based_loss, _acc=(acc32, mode))
             off += n
         return dq
     a, b, c, keep = _ca_params(q, k, heads, frames, layout, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
                                com_loss_scale=com_loss_scale, loss_partial=loss_partial, want_dq=want_dq, use_ratio_based_loss=use_ratio_based_loss,
                                attn_sync_weight=attn_sync_weight, boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed,
-                               boxdiff_L=boxdiff_L, _acc=_acc)
+                               boxdiff_L=boxdiff_L, use_max_based_loss=use_max_based_loss, use_ce_based_loss=use_ce_based_loss, _acc=_acc)
     st = torch.cuda.current_stream().cuda_stream
     hip.check(hip.lib().lvdhip_ca_probs(C.byref(a), st), "ca_probs")
     hip.check(hip.lib().lvdhip_ca_select(C.byref(b), st), "ca_select")
@@ -123,7 +169,8 @@ def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext,
 
 
 def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_weight, com_loss_scale, loss_partial, want_dq,
-               use_ratio_based_loss, attn_sync_weight, boxdiff_loss_scale, boxdiff_normed, boxdiff_L, _acc=None, dq_out=None):
+               use_ratio_based_loss, attn_sync_weight, boxdiff_loss_scale, boxdiff_normed, boxdiff_L, use_max_based_loss=True,
+               use_ce_based_loss=False, _acc=None, dq_out=None):
     """The three parameter blocks of one key (probabilities, selection / loss, dQ) and the buffers they point into (`keep`)."""
     dev = q.device
     P = layout.H * layout.W
@@ -143,7 +190,7 @@ def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_
     b.tok_obj, b.boxes, b.tok_weight, b.nobj = layout.tok_obj.data_ptr(), layout.boxes.data_ptr(), layout.tok_weight.data_ptr(), layout.nobj
     b.fg_weight, b.bg_weight, b.com_loss_scale, b.grad_scale = fg_weight, bg_weight, com_loss_scale, grad_scale
     b.loss_partial, b.com_ws = loss_partial.data_ptr(), com_ws.data_ptr()
-    b.use_ratio_loss, b.ratio_eps, b.attn_sync_weight = int(bool(use_ratio_based_loss)), 1.0e-2, float(attn_sync_weight)
+    b.use_ratio_loss, b.ratio_eps, b.attn_sync_weight = _energy_form(use_ratio_based_loss, use_max_based_loss, use_ce_based_loss), 1.0e-2, float(attn_sync_weight)
     b.boxdiff_loss_scale, b.boxdiff_normed, b.boxdiff_L = float(boxdiff_loss_scale), int(bool(boxdiff_normed)), int(boxdiff_L)
     if use_ratio_based_loss:
         warnings.warn("Using ratio-based loss, which is deprecated. Max-based loss is recommended. The scale may be different.")
@@ -244,9 +291,8 @@ def guidance_loss_and_grad(engine: HipUNet3D, latents, t, text, bboxes, object_p
     if saved_attn is not None:  # visualisation only (return_saved_attn): the full maps, as AttnProcessor.__call__ would have saved them
         for key in keys:
             q, k, heads, g = collect["q"][key]
-            qf = q.float().reshape(g.B * g.F, g.HW, heads, 64).permute(0, 2, 1, 3)
-            kf = k.float().reshape(text.B, text.ntext, heads, 64).permute(0, 2, 3, 1).repeat_interleave(g.F, 0)
-            saved_attn[key] = (qf @ kf * 0.125).softmax(-1).cpu()
+            saved_attn[key] = ca_probability_maps(q, k, samples=g.B * g.F, heads=heads, positions=g.HW, ntext=text.ntext,
+                                                  samples_per_key=g.F).cpu()
     loss = ops.reduce_sum(partial, grad_scale)
     tape.backward()
     g0 = Geom(1, frames, latents.shape[3], latents.shape[4])

@@ -115,6 +115,22 @@ class CaProbsParams(C.Structure):
     ]
 
 
+class CaProbsFullParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", i32), ("k", C.c_void_p), ("ldk", i32),
+        ("samples", i32), ("heads", i32), ("P", i32), ("ntext", i32), ("samples_per_key", i32), ("scale", f32),
+        ("probs", C.c_void_p),
+    ]
+
+
+class CaApplyProbsParams(C.Structure):
+    _fields_ = [
+        ("probs", C.c_void_p), ("v", C.c_void_p), ("ldv", i32),
+        ("samples", i32), ("heads", i32), ("P", i32), ("ntext", i32), ("samples_per_key", i32),
+        ("out", C.c_void_p), ("ldo", i32),
+    ]
+
+
 class CaSelectParams(C.Structure):
     _fields_ = [
         ("probs", C.c_void_p), ("dprobs", C.c_void_p),
@@ -159,6 +175,8 @@ SYMBOLS = {
     "lvdhip_attention_fwd": [_P(AttnParams), C.c_void_p],
     "lvdhip_attention_bwd": [_P(AttnBwdParams), C.c_void_p],
     "lvdhip_ca_probs": [_P(CaProbsParams), C.c_void_p],
+    "lvdhip_ca_probs_full": [_P(CaProbsFullParams), C.c_void_p],
+    "lvdhip_ca_apply_probs": [_P(CaApplyProbsParams), C.c_void_p],
     "lvdhip_ca_select": [_P(CaSelectParams), C.c_void_p],
     "lvdhip_ca_dq": [_P(CaDqParams), C.c_void_p],
     "lvdhip_ca_probs_multi": [_P(CaProbsParams), i32, C.c_void_p],
@@ -190,7 +208,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 104
+ABI_VERSION = 105
 CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 

@@ -4,8 +4,11 @@
 Same call contract as AttnProcessor.__call__ (:432-449, including the `return_attntion_probs` spelling): given an
 `Attention`-like module (`.to_q/.to_k/.to_v/.to_out[0]` Linear layers, `.heads`), hidden states (B, L, C) and optional
 encoder states (B, T, D) it returns the attended hidden states; when the key is listed in `save_keys` the probabilities
-(B, heads, L, T) are stored in `save_attn_to_dict[tuple(attn_key)]`.  Constraints of the kernels: CUDA tensors, head
-dim 64, no attention mask (the reference never passes one on this path, unet_3d_blocks.py:406 TODO)."""
+(B, heads, L, T) are stored in `save_attn_to_dict[tuple(attn_key)]`; an `attn_process_fn` rewrites the cross-attention
+probabilities before they meet V (:537-549).  Every branch runs on the C ABI: the fused attention (`lvdhip_attention_fwd`), the
+materialised map of the slow path (`lvdhip_ca_probs_full`) and the product of processed probabilities with V
+(`lvdhip_ca_apply_probs`).  Constraints of the kernels: CUDA tensors, head dim 64, no attention mask (the reference never
+passes one on this path, unet_3d_blocks.py:406 TODO)."""
 import torch
 
 from .. import ops
@@ -26,8 +29,8 @@ class HipAttnProcessor:
                  attn_key=None, attn_process_fn=None, return_cond_ca_only=False, return_token_ca_only=None,
                  offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None, enable_flash_attn=True,
                  cross_attn_save_hidden_states=False):
-        if attention_mask is not None or attn_process_fn is not None:
-            raise NotImplementedError("attention_mask / attn_process_fn are not supported by the fused HIP attention")
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is not supported by the HIP attention kernels (the reference passes none on this path)")
         if hidden_states.dim() != 3 or not hidden_states.is_cuda:
             raise ValueError("HipAttnProcessor expects CUDA hidden states of shape (batch, tokens, channels)")
         B, L, Cc = hidden_states.shape
@@ -43,16 +46,26 @@ class HipAttnProcessor:
         wv, _ = _w(attn.to_v)
         wo, bo = _w(attn.to_out[0])
         q, k, v = ops.gemm(x, wq), ops.gemm(ctx, wk), ops.gemm(ctx, wv)
-        o = torch.empty_like(q)
-        ops.attention_fwd(q, k, v, o, samples=B, heads=heads, sq=L, skv=T, qmap=ops.RowMap(1, L, 0, 1), kvmap=ops.RowMap(1, T, 0, 1),
-                          scale=float(getattr(attn, "scale", 0.125)))
-        out = ops.gemm(o, wo, bias=bo).reshape(B, L, Cc).to(hidden_states.dtype)
+        scale = float(getattr(attn, "scale", 0.125))
+        if cross and cross_attn_save_hidden_states:
+            self.hidden_states = hidden_states  # models/attention_processor.py:456-457
         want = return_attntion_probs or (save_attn_to_dict is not None and (save_keys is None or tuple(attn_key) in save_keys))
-        if cross and want:
-            # probabilities are only materialised on request (visualisation / external losses); fp32 like the loss maths
-            qf = q.float().reshape(B, L, heads, 64).permute(0, 2, 1, 3)
-            kf = k.float().reshape(B, T, heads, 64).permute(0, 2, 3, 1)
-            probs = (qf @ kf * float(getattr(attn, "scale", 0.125))).softmax(-1)
+        probs = None
+        if cross and (want or attn_process_fn is not None):
+            # probabilities are only materialised on request (visualisation / external losses / a caller's rewrite); fp32 like the loss maths
+            from ..guidance import ca_apply_probabilities, ca_probability_maps
+            probs = ca_probability_maps(q, k, samples=B, heads=heads, positions=L, ntext=T, scale=scale)
+        if cross and attn_process_fn is not None:
+            # :537-549 — the callback sees (batch*heads, L, T) probabilities and head-batched q / k / v, and returns what meets V
+            hb = lambda t, n: t.reshape(B, n, heads, 64).permute(0, 2, 1, 3).reshape(B * heads, n, 64)
+            processed = attn_process_fn(probs.reshape(B * heads, L, T).clone(), hb(q, L), hb(k, T), hb(v, T), attn_key=attn_key, cross_attn=cross,
+                                        batch_size=B, heads=heads)
+            o = ca_apply_probabilities(processed, v, samples=B, heads=heads, positions=L, ntext=T)
+        else:
+            o = torch.empty_like(q)
+            ops.attention_fwd(q, k, v, o, samples=B, heads=heads, sq=L, skv=T, qmap=ops.RowMap(1, L, 0, 1), kvmap=ops.RowMap(1, T, 0, 1), scale=scale)
+        out = ops.gemm(o, wo, bias=bo).reshape(B, L, Cc).to(hidden_states.dtype)
+        if probs is not None and (return_attntion_probs or save_attn_to_dict is not None):  # :553-589, on the probabilities BEFORE the rewrite
             if return_token_ca_only is not None:
                 probs = probs[..., return_token_ca_only:return_token_ca_only + 1] if isinstance(return_token_ca_only, int) else probs[..., return_token_ca_only]
             if return_cond_ca_only:
@@ -65,6 +78,10 @@ class HipAttnProcessor:
             if return_attntion_probs:
                 return out, probs
         return out
+
+    def free(self):
+        if hasattr(self, "hidden_states"):
+            del self.hidden_states
 
 
 AttentionProcessor = HipAttnProcessor

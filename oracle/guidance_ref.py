@@ -35,10 +35,10 @@ def _com(x, h_range, w_range):
 
 def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
                     bg_weight=1.0, com_loss_scale=0.0, use_ratio_based_loss=False, eps=1.0e-2, attn_sync_weight=0.0,
-                    boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1):
+                    boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, use_max_based_loss=True, use_ce_based_loss=False):
     """attn_map: (frames, heads, P, tokens) probabilities.  Returns the un-normalised loss contribution.
     utils/guidance.py:160-526 (add_ca_loss_per_attn_map_to_loss) with upsample_scale = 1, no smoothing / renorm / CE:
-    max-based top-k energy (default) or the deprecated ratio-based energy (:312-323), attention sync between consecutive frames
+    max-based top-k energy (default), the deprecated ratio-based energy (:312-323) or the CE / NLL form (:363-399), attention sync between consecutive frames
     (:401-430), BoxDiff corner constraint (:240-287, 433-465), centre-of-mass position / velocity terms (:467-522)."""
     n_f, heads, P, _ = attn_map.shape
     H, W = get_hw_from_attn_dim(P, base_attn_dim)
@@ -75,9 +75,15 @@ def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=
                 if use_ratio_based_loss:
                     act = (a.view(heads, H, W) * mask).reshape(heads, -1).sum(-1) / (a.sum(-1) + eps)
                     obj_loss = obj_loss + torch.mean((1 - act) ** 2)
-                else:
+                elif use_max_based_loss:
                     obj_loss = obj_loss + fg_weight * (1 - (a * m1).topk(k_fg).values.mean(1)).sum(0)
                     obj_loss = obj_loss + bg_weight * (a * (1 - m1)).topk(k_bg).values.mean(1).sum(0)
+                elif use_ce_based_loss:
+                    ac = torch.clamp(a, min=eps, max=1 - eps)
+                    obj_loss = obj_loss + fg_weight * (-torch.log(torch.clamp((m1 * ac).topk(k_fg).values, min=eps))).mean(1).sum(0)
+                    obj_loss = obj_loss + bg_weight * (-torch.log(1 - ((1 - m1) * ac).topk(k_bg).values.mean(1))).sum(0)
+                else:
+                    raise ValueError("Unknown loss: no loss selected")
                 if attn_sync_weight != 0.0 and f != n_f - 1:
                     a2 = attn_map[f + 1, :, :, pos].float()
                     d = a.view(heads, H, W)[:, y0:y1, x0:x1] - a2.view(heads, H, W)[:, y0:y1, x0:x1]

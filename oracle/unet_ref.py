@@ -20,6 +20,9 @@ import torch
 import torch.nn.functional as F
 
 
+PROBS_BYTES_PER_CHUNK = 1 << 30  # attention() materialises at most this many bytes of probabilities at a time when nobody asks for them
+
+
 def _lin(sd, name, x):
     return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
 
@@ -47,10 +50,16 @@ def attention(sd, name, x, ctx, heads, on_probs=None):
     d = c // heads
     sp = lambda t: t.reshape(b, -1, heads, d).permute(0, 2, 1, 3)
     q, k, v = sp(q), sp(k), sp(v)
-    probs = (q @ k.transpose(-1, -2) * d**-0.5).softmax(-1)
-    if on_probs is not None:
-        on_probs(probs)  # (batch, heads, queries, keys)
-    o = (probs @ v).permute(0, 2, 1, 3).reshape(b, lq, c)
+    step = max(1, PROBS_BYTES_PER_CHUNK // (heads * lq * k.shape[2] * 4))
+    if on_probs is None and not torch.is_grad_enabled() and step < b:
+        # same arithmetic, batch rows taken a few at a time: the 576x320x24 forward would hold 8 GB of probabilities per level-0 layer
+        o = torch.cat([(q[i:i + step] @ k[i:i + step].transpose(-1, -2) * d**-0.5).softmax(-1) @ v[i:i + step] for i in range(0, b, step)])
+    else:
+        probs = (q @ k.transpose(-1, -2) * d**-0.5).softmax(-1)
+        if on_probs is not None:
+            on_probs(probs)  # (batch, heads, queries, keys)
+        o = probs @ v
+    o = o.permute(0, 2, 1, 3).reshape(b, lq, c)
     return _lin(sd, name + ".to_out.0", o)
 
 

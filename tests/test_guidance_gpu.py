@@ -133,7 +133,7 @@ def test_fused_loss_map_sizes_and_prompt_lengths(Hh, Ww, nt):
     assert rel(dq, gq) < 1.5e-2, rel(dq, gq)
 
 
-@pytest.mark.parametrize("case", ["ratio", "sync", "boxdiff", "boxdiff_sum", "all"])
+@pytest.mark.parametrize("case", ["ratio", "sync", "boxdiff", "boxdiff_sum", "all", "ce", "ce_com"])
 def test_fused_loss_optional_terms_vs_oracle_and_reference(case):
     """Ratio-based energy, attention sync, BoxDiff corner constraint in the fused kernel: (i) on projected Q/K vs autograd through
     the oracle, (ii) on the reference's own maps: the kernel's loss / dA against the golden loss / gradient of utils/guidance.py."""
@@ -355,3 +355,25 @@ def test_batched_guidance_pass_keeps_the_samples_independent():
     (ka, kb), (lka, lkb) = many([la, lb], [ca, cb], [ba, bb], [pa, pb], [torch.tensor(0.0), torch.tensor(10000.0)])
     assert torch.equal(ka, la) and float(lka) == 0.0
     assert rel(kb - lb, nb - lb) < 8e-2
+
+
+@pytest.mark.parametrize("samples,heads,P,ntext,spk", [(6, 2, 50, 77, 1), (8, 5, 180, 77, 4), (3, 10, 720, 77, 3), (2, 1, 33, 96, 1), (4, 3, 129, 20, 2)])
+def test_full_probability_maps_and_their_product_with_v(samples, heads, P, ntext, spk):
+    """The slow path of the plug-in on the C ABI (models/attention_processor.py:515-552): `lvdhip_ca_probs_full` materialises
+    softmax(scale Q K^T) over all text positions as (samples, heads, P, tokens) fp32; `lvdhip_ca_apply_probs` multiplies a map held in
+    memory with V.  Against fp32 torch on the same bf16 inputs: the map to 2e-3 absolute (bf16 MFMA scores, exp2), rows sum to 1; the
+    product to bf16 rounding.  Tile tails (P not a multiple of 32 or 64), shared text keys (samples_per_key = frames) and short prompts."""
+    gen = torch.Generator().manual_seed(samples * 1000 + P)
+    q = torch.randn(samples * P, heads * 64, generator=gen).cuda().bfloat16()
+    k = torch.randn((samples // spk) * ntext, heads * 64, generator=gen).cuda().bfloat16()
+    v = torch.randn((samples // spk) * ntext, heads * 64, generator=gen).cuda().bfloat16()
+    probs = guidance.ca_probability_maps(q, k, samples=samples, heads=heads, positions=P, ntext=ntext, samples_per_key=spk)
+    qf = q.float().reshape(samples, P, heads, 64).permute(0, 2, 1, 3)
+    sel = lambda t: t.float().reshape(samples // spk, ntext, heads, 64).permute(0, 2, 1, 3).repeat_interleave(spk, 0)
+    ref = (qf @ sel(k).transpose(-1, -2) * 0.125).softmax(-1)
+    assert probs.shape == ref.shape and float((probs - ref).abs().max()) < 2e-3
+    assert float((probs.sum(-1) - 1).abs().max()) < 1e-5
+    noisy = (ref + 0.01 * torch.rand(ref.shape, generator=torch.Generator().manual_seed(1)).cuda()).contiguous()  # any fp32 map, not only a softmax
+    out = guidance.ca_apply_probabilities(noisy, v, samples=samples, heads=heads, positions=P, ntext=ntext, samples_per_key=spk)
+    want = (noisy @ sel(v)).permute(0, 2, 1, 3).reshape(samples * P, heads * 64)
+    assert rel(out, want) < 4e-3

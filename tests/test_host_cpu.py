@@ -32,13 +32,13 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     """Field order/size drift between include/lvdhip.h and the ctypes mirrors would corrupt launches silently."""
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "lvdhip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lvd_gemm_params), sizeof(lvd_gn_stats_params), sizeof(lvd_gn_apply_params), sizeof(lvd_gn_bwd_stats_params), sizeof(lvd_gn_bwd_apply_params), sizeof(lvd_ln_params), sizeof(lvd_ln_bwd_params), sizeof(lvd_attn_params), sizeof(lvd_attn_bwd_params), sizeof(lvd_ca_probs_params), sizeof(lvd_ca_select_params), sizeof(lvd_ca_dq_params));return 0;}'
+    src = '#include <stdio.h>\n#include "lvdhip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lvd_gemm_params), sizeof(lvd_gn_stats_params), sizeof(lvd_gn_apply_params), sizeof(lvd_gn_bwd_stats_params), sizeof(lvd_gn_bwd_apply_params), sizeof(lvd_ln_params), sizeof(lvd_ln_bwd_params), sizeof(lvd_attn_params), sizeof(lvd_attn_bwd_params), sizeof(lvd_ca_probs_params), sizeof(lvd_ca_select_params), sizeof(lvd_ca_dq_params), sizeof(lvd_ca_probs_full_params), sizeof(lvd_ca_apply_probs_params));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
         sizes = list(map(int, subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()))
     mirrors = [hip.GemmParams, hip.GnStatsParams, hip.GnApplyParams, hip.GnBwdStatsParams, hip.GnBwdApplyParams, hip.LnParams, hip.LnBwdParams,
-               hip.AttnParams, hip.AttnBwdParams, hip.CaProbsParams, hip.CaSelectParams, hip.CaDqParams]
+               hip.AttnParams, hip.AttnBwdParams, hip.CaProbsParams, hip.CaSelectParams, hip.CaDqParams, hip.CaProbsFullParams, hip.CaApplyProbsParams]
     assert sizes == [ctypes.sizeof(m) for m in mirrors]
 
 
@@ -163,7 +163,10 @@ def test_guidance_layout_matches_oracle_box_logic():
         assert list(arr[f]) == [x0, y0, x1, y1, kfg, kbg]
     assert lay.tok_ids.tolist() == [2, 5] and lay.tok_weight.tolist() == [0.5, 0.5]
     with pytest.raises(NotImplementedError):
-        guidance.hip_latent_backward_guidance(None, None, None, 0, boxes, [[2]], 1, None, 1.0, use_ce_based_loss=True)  # CE / smoothing / renorm variants are not built
+        guidance.hip_latent_backward_guidance(None, None, None, 0, boxes, [[2]], 1, None, 1.0, smooth_attn=True)  # smoothing / renorm / upsampled-map variants are not built
+    assert [guidance._energy_form(*a) for a in ((False, True, False), (True, True, True), (False, False, True))] == [0, 1, 2]  # the chain of utils/guidance.py:312,346,363
+    with pytest.raises(ValueError, match="no loss selected"):
+        guidance._energy_form(False, False, False)
     with pytest.raises(KeyError):
         guidance._last_key_in_order(type("E", (), {"cfg": UNetConfig(**TINY)})(), [("down", 3, 0, 0)])
 

@@ -79,6 +79,8 @@ LOSS_VARIANTS = {  # the cases of oracle/make_golden.py section (c), second box 
     "boxdiff": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, boxdiff_loss_scale=0.7, boxdiff_normed=True),
     "boxdiff_sum": dict(fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, boxdiff_loss_scale=0.05, boxdiff_normed=False, boxdiff_L=2),
     "all": dict(fg_top_p=0.3, bg_top_p=0.6, fg_weight=1.5, bg_weight=2.5, attn_sync_weight=1.0, boxdiff_loss_scale=0.4, com_loss_scale=0.03),
+    "ce": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0),
+    "ce_com": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.25, bg_top_p=0.4, fg_weight=1.5, bg_weight=0.5, com_loss_scale=0.03),
 }
 
 

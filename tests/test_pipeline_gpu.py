@@ -65,6 +65,44 @@ def test_attn_processor_plugin():
     assert out_self.shape == x.shape and torch.isfinite(out_self).all()
     with pytest.raises(NotImplementedError):
         proc(attn, x, encoder_hidden_states=ctx, attention_mask=torch.ones(3, 77, device="cuda"))
+    # slicing / pairing options of the saved map (models/attention_processor.py:566-583)
+    o2, p2 = proc(attn, x[:2], encoder_hidden_states=ctx[:2], attn_key=["up", 1, 0, 0], return_attntion_probs=True, return_token_ca_only=5,
+                  return_cond_ca_only=True, offload_cross_attn_to_cpu=True)
+    assert p2.device.type == "cpu" and p2.shape == (1, 2, 50, 1) and rel(p2, probs[1:2, :, :, 5:6]) < 2e-2 and rel(o2, ref[:2]) < 2e-2
+    _, p3 = proc(attn, x, encoder_hidden_states=ctx, attn_key=["up", 1, 0, 0], return_attntion_probs=True, return_token_ca_only=torch.tensor([2, 7], device="cuda"))
+    assert p3.shape == (3, 2, 50, 2) and rel(p3, probs[..., [2, 7]]) < 2e-2
+
+
+def test_attn_processor_attn_process_fn():
+    """`attn_process_fn` (models/attention_processor.py:537-549): the callback receives the (batch*heads, L, T) cross-attention probabilities
+    with head-batched q / k / v and its return value is what multiplies V; the map saved / returned is the one BEFORE the rewrite (:553-556).
+    Self-attention never calls it (:459-474)."""
+    torch.manual_seed(1)
+    attn = _Attn(128, 96, 2).cuda()
+    x, ctx = torch.randn(2, 70, 128, device="cuda"), torch.randn(2, 77, 96, device="cuda")
+    proc = HipAttnProcessor()
+    seen = {}
+
+    def boost_token_3(p, query, key, value, attn_key=None, cross_attn=None, batch_size=None, heads=None):
+        seen.update(shape=tuple(p.shape), q=tuple(query.shape), k=tuple(key.shape), v=tuple(value.shape), key=attn_key, cross=cross_attn, b=batch_size, h=heads)
+        p = p.clone()
+        p[:, :, 3] += 0.5
+        return p / p.sum(-1, keepdim=True)
+
+    saved = {}
+    out = proc(attn, x, encoder_hidden_states=ctx, attn_key=["mid", 0, 0, 0], attn_process_fn=boost_token_3, save_attn_to_dict=saved, save_keys=[("mid", 0, 0, 0)])
+    assert seen == dict(shape=(4, 70, 77), q=(4, 70, 64), k=(4, 77, 64), v=(4, 77, 64), key=["mid", 0, 0, 0], cross=True, b=2, h=2)
+    q, k, v = attn.to_q(x), attn.to_k(ctx), attn.to_v(ctx)
+    sp = lambda t: t.reshape(2, -1, 2, 64).permute(0, 2, 1, 3)
+    probs = (sp(q) @ sp(k).transpose(-1, -2) * 0.125).softmax(-1)
+    rewritten = boost_token_3(probs.reshape(4, 70, 77), sp(q).reshape(4, 70, 64), sp(k).reshape(4, 77, 64), sp(v).reshape(4, 77, 64)).reshape(2, 2, 70, 77)
+    ref = attn.to_out[0]((rewritten @ sp(v)).permute(0, 2, 1, 3).reshape(2, 70, 128))
+    plain = attn.to_out[0]((probs @ sp(v)).permute(0, 2, 1, 3).reshape(2, 70, 128))
+    assert rel(out, ref) < 2e-2 and rel(out, plain) > 5 * rel(out, ref)
+    assert rel(saved[("mid", 0, 0, 0)], probs) < 2e-2  # the map before the rewrite
+    called = []
+    proc(_Attn(128, 128, 2).cuda(), x, attn_key=["in", 0, 0], attn_process_fn=lambda *a, **kw: called.append(1))
+    assert not called
 
 
 def test_pipeline_guided_sampling_vs_oracle_loop():
