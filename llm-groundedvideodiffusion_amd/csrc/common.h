@@ -51,7 +51,11 @@ LVD_DEV float erf_as_f(float x) {
   const float e = fast_exp2(-1.4426950408889634f * a * a);
   return copysignf(fmaf(-pl * t, e, 1.f), x);
 }
+#ifdef LVD_GELU_ABL  // developer ablation (never in the shipped library): what the GELU arithmetic costs inside the GEGLU epilogues
+LVD_DEV float gelu_erf_f(float x) { return x; }
+#else
 LVD_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erf_as_f(x * 0.70710678118654752f)); }
+#endif
 LVD_DEV float gelu_erf_grad_f(float x) {
   float cdf = 0.5f * (1.f + erf_as_f(x * 0.70710678118654752f));
   float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

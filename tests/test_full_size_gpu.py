@@ -112,7 +112,10 @@ def test_headline_guidance_iteration_vs_oracle_autograd(full, oracle_threads):
     print(f"576x320x24 guidance iteration vs oracle autograd ({dt:.0f} s, MemAvailable was {have:.0f} GB): loss {float(loss):.5f} vs {ref_loss:.5f}; "
           f"update rel-L2 {rel(d, d_ref):.4f}, cosine {cos:.5f}")
     assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
-    assert rel(d, d_ref) < 0.08 and cos > 0.996  # bf16-storage noise floor of this topology: 4.5 % (tests/test_noise_floor.py)
+    # Yardstick: the fp32 oracle with activations / activation gradients rounded to bf16 where the product stores them (oracle/bf16_storage.py)
+    # is 0.0729 away from the fp32 oracle on exactly this problem (tools/full_size_oracle_probe.py --floor, gpurun_out -> profiles/r06_full_size_parity.txt);
+    # the HIP path measured 0.0727, cosine 0.99736.  Bound = 1.4 x that floor.
+    assert rel(d, d_ref) < 0.10 and cos > 0.995
 
 
 def test_headline_gated_cfg_forward_vs_oracle(oracle_threads):
