@@ -51,11 +51,44 @@ LVD_DEV float erf_as_f(float x) {
   const float e = fast_exp2(-1.4426950408889634f * a * a);
   return copysignf(fmaf(-pl * t, e, 1.f), x);
 }
-#ifdef LVD_GELU_ABL  // developer ablation (never in the shipped library): what the GELU arithmetic costs inside the GEGLU epilogues
-LVD_DEV float gelu_erf_f(float x) { return x; }
-#else
 LVD_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erf_as_f(x * 0.70710678118654752f)); }
+// GELU for the GEGLU epilogues of the GEMM kernels, two values per lane in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two FMAs per issue slot).
+// The A&S form above costs ~21 issue slots per value (two quarter-rate transcendentals: v_rcp, v_exp) and the epilogue of a feed-forward
+// tile evaluates it 20 480 times per wave: with the GELU compiled out the level-0 / 1 / 2 GEGLU products run 331 -> 274, 255 -> 222,
+// 242 -> 219 us (profiles/r06_geglu_epilogue.txt).  Here: Phi(x) = 1/2 + x Q(x^2) on |x| <= 4.25 with Q of degree 8 (weighted minimax
+// fit of x Phi(x), tools/gelu_fit.py), x clamped into the interval for Phi only: ~7 slots per value, no transcendental.
+// |gelu - exact| <= 3.7e-5 for |x| <= 4.25 and <= 5e-5 out to |x| = 12: an order below the fp16 rounding of the reference's own
+// activations (2^-11 relative) and two below the bf16 rounding of the stored product.  The element-wise kernels keep the A&S form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+LVD_DEV f32x2 gelu_pk2(f32x2 x) {
+#ifdef LVD_GELU_ABL  // developer ablation (never in the shipped library): what the GELU arithmetic costs inside the GEGLU epilogues
+  return x;
+#else
+  const float L = 4.25f;
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -L, L), __builtin_amdgcn_fmed3f(x.y, -L, L)};
+  const f32x2 s = xc * xc;
+  f32x2 q = (f32x2)(4.5474263243860946e-11f);
+  q = __builtin_elementwise_fma(q, s, (f32x2)(-4.515573248653482e-09f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(1.9862437738993322e-07f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(-5.147656338522211e-06f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(8.849051664583385e-05f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(-0.0010790855158120394f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(0.009718801826238632f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(-0.06619030982255936f));
+  q = __builtin_elementwise_fma(q, s, (f32x2)(0.398819237947464f));
+  return x * __builtin_elementwise_fma(xc, q, (f32x2)(0.5f));
 #endif
+}
+// hidden * gelu(gate) for four adjacent columns -> four bf16 (the GEGLU of models/attention.py:355-376 as the epilogues apply it)
+template <class V4>
+LVD_DEV uint2 geglu4(const V4& h, const V4& g) {
+  const f32x2 a = (f32x2){h[0], h[1]} * gelu_pk2((f32x2){g[0], g[1]});
+  const f32x2 b = (f32x2){h[2], h[3]} * gelu_pk2((f32x2){g[2], g[3]});
+  uint2 o;
+  o.x = pack2bf(a.x, a.y);
+  o.y = pack2bf(b.x, b.y);
+  return o;
+}
 LVD_DEV float gelu_erf_grad_f(float x) {
   float cdf = 0.5f * (1.f + erf_as_f(x * 0.70710678118654752f));
   float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

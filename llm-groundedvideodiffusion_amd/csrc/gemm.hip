@@ -234,8 +234,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
         }
         int oc = (nbase >> 1) + cq * 4;
         uint2 o;
-        o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-        o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+        o = geglu4(h, g);
         stg8(out + (long)m * ldc + oc, o);
       }
       continue;

@@ -280,8 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const lvd_gemm_para
                 g[e] = fmaf(mr[i].y, fmaf(-mr[i].x, ls[u][1][e], g[e]), lb[u][1][e]);
               }
             }
-            o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-            o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+            o = geglu4(h, g);
           } else {
             const int j = c8 >> 2, q = c8 & 3;
             f32x4 v;

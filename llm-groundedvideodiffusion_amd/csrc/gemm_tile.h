@@ -208,8 +208,7 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * b][4 * q + e]; g[e] = acc[i][2 * b + 1][4 * q + e]; }
           uint2 o;
-          o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-          o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+          o = geglu4(h, g);
           stg8(orow + (nbase >> 1) + b * 32 + 8 * q + 4 * hi, o);
         }
       continue;
@@ -327,8 +326,7 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
             }
           }
           uint2 o;
-          o.x = pack2bf(h[0] * gelu_erf_f(g[0]), h[1] * gelu_erf_f(g[1]));
-          o.y = pack2bf(h[2] * gelu_erf_f(g[2]), h[3] * gelu_erf_f(g[3]));
+          o = geglu4(h, g);
           *reinterpret_cast<uint2*>(wrow + b * 16 + 4 * q + 2 * hi) = o;
         }
     } else {
