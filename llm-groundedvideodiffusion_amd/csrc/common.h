@@ -79,6 +79,12 @@ LVD_DEV f32x2 gelu_pk2(f32x2 x) {
   return x * __builtin_elementwise_fma(xc, q, (f32x2)(0.5f));
 #endif
 }
+// LayerNorm fold of four adjacent columns, rstd * (v - mean * colsum) + bias, as two v_pk_fma_f32 pairs (same roundings as the scalar
+// fmaf(rstd, fmaf(-mean, s, v), b) it replaces: 1 issue slot per value instead of 2)
+template <class V4>
+LVD_DEV V4 ln_fold4(const V4& v, float mean, float rstd, const V4& s, const V4& b) {
+  return __builtin_elementwise_fma((V4)(rstd), __builtin_elementwise_fma((V4)(-mean), s, v), b);
+}
 // hidden * gelu(gate) for four adjacent columns -> four bf16 (the GEGLU of models/attention.py:355-376 as the epilogues apply it)
 template <class V4>
 LVD_DEV uint2 geglu4(const V4& h, const V4& g) {

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const lvd_gemm_params p
       f32x4 v = *reinterpret_cast<const f32x4*>(&S[row * 64 + cq * 4]);
       v += bias4;
       if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m / p.rows_per_sample) * (p.ldrowbias ? p.ldrowbias : p.N) + n);
-      v *= p.alpha;
+      if (p.alpha != 1.f) v *= p.alpha;
       if (p.res) {
         uint2 r = rres[it];
         v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);

@@ -274,11 +274,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const lvd_gemm_para
 #pragma unroll
             for (int e = 0; e < 4; ++e) { h[e] = acc[i][2 * bb][4 * q + e]; g[e] = acc[i][2 * bb + 1][4 * q + e]; }
             if constexpr (LNF) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                h[e] = fmaf(mr[i].y, fmaf(-mr[i].x, ls[u][0][e], h[e]), lb[u][0][e]);
-                g[e] = fmaf(mr[i].y, fmaf(-mr[i].x, ls[u][1][e], g[e]), lb[u][1][e]);
-              }
+              h = ln_fold4(h, mr[i].x, mr[i].y, ls[u][0], lb[u][0]);
+              g = ln_fold4(g, mr[i].x, mr[i].y, ls[u][1], lb[u][1]);
             }
             o = geglu4(h, g);
           } else {
@@ -287,10 +284,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const lvd_gemm_para
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
             if constexpr (LNF) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaf(mr[i].y, fmaf(-mr[i].x, ls[u][0][e], v[e]), lb[u][0][e]);
+              v = ln_fold4(v, mr[i].x, mr[i].y, ls[u][0], lb[u][0]);
             }
-            v *= p.alpha;
+            if (p.alpha != 1.f) v *= p.alpha;
             o.x = pack2bf(v[0], v[1]);
             o.y = pack2bf(v[2], v[3]);
           }

@@ -222,7 +222,7 @@ LVD_DEV void ring_epilogue(const lvd_gemm_params& p, const f32x16 (&acc)[FM][FN]
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-        v *= p.alpha;
+        if (p.alpha != 1.f) v *= p.alpha;  // wave-uniform: only the GLIGEN gates scale a product
         if (p.res) {
           uint2 r = ldg8(p.res + (long)m * p.ldres + n);
           v[0] += bflo(r.x); v[1] += bfhi(r.x); v[2] += bflo(r.y); v[3] += bfhi(r.y);
@@ -319,11 +319,8 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
             const int nl = b * 64 + 8 * q + 4 * hi;
             const f32x4 sh = *reinterpret_cast<const f32x4*>(ln->s + nl), sg = *reinterpret_cast<const f32x4*>(ln->s + nl + 32);
             const f32x4 bh = *reinterpret_cast<const f32x4*>(ln->b + nl), bg = *reinterpret_cast<const f32x4*>(ln->b + nl + 32);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              h[e] = fmaf(ln->rstd[i], fmaf(-ln->mean[i], sh[e], h[e]), bh[e]);
-              g[e] = fmaf(ln->rstd[i], fmaf(-ln->mean[i], sg[e], g[e]), bg[e]);
-            }
+            h = ln_fold4(h, ln->mean[i], ln->rstd[i], sh, bh);
+            g = ln_fold4(g, ln->mean[i], ln->rstd[i], sg, bg);
           }
           uint2 o;
           o = geglu4(h, g);
@@ -341,10 +338,9 @@ LVD_DEV void ring_epilogue_rows(const lvd_gemm_params& p, const f32x16 (&acc)[FM
           if constexpr (LN) {
             const int nl = j * 32 + 8 * q + 4 * hi;
             const f32x4 sv = *reinterpret_cast<const f32x4*>(ln->s + nl), bv = *reinterpret_cast<const f32x4*>(ln->b + nl);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(ln->rstd[i], fmaf(-ln->mean[i], sv[e], v[e]), bv[e]);
+            v = ln_fold4(v, ln->mean[i], ln->rstd[i], sv, bv);
           }
-          v *= p.alpha;
+          if (p.alpha != 1.f) v *= p.alpha;  // wave-uniform: only the GLIGEN gates scale a product
           uint2 o;
           o.x = pack2bf(v[0], v[1]);
           o.y = pack2bf(v[2], v[3]);
@@ -481,7 +477,7 @@ LVD_DEV void splitk_reduce_quad(const lvd_gemm_params& p, const float* s0, long 
   }
   if (p.bias) v += bv;
   if (p.rowbias) v += rbv;
-  v *= p.alpha;
+  if (p.alpha != 1.f) v *= p.alpha;  // wave-uniform: only the GLIGEN gates scale a product
   if (p.res) { v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y); }
   if (p.out_fp32) {
     if (p.accumulate) v += av32;
