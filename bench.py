@@ -386,7 +386,10 @@ def main():
     # launch stream (GemmTimer; no extra synchronisation)
     gt = GemmTimer()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # step boundaries on the launch stream
+    guidance.loss_kernel_events = []  # the fused guidance-loss launches (3 per iteration) between events on the launch stream
+    from lvd_amd import hip as _hip
     sync()
+    calls0 = _hip.calls
     t0 = time.perf_counter()
     with gt:
         marks[0].record()
@@ -395,6 +398,8 @@ def main():
             marks[k + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    abi_calls_per_step = (_hip.calls - calls0) / args.steps
+    loss_events, guidance.loss_kernel_events = guidance.loss_kernel_events, None
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     med = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if dist is not None:
@@ -438,11 +443,27 @@ def main():
                 traffic = {"hbm_side_bytes_per_launch": tj["fetch_bytes"] + tj["write_bytes"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes"],
                            "ratio": round((tj["fetch_bytes"] + tj["write_bytes"]) / tj["algorithmic_bytes"], 3), "shape": tj["shape"]}
                 tnote = tj.get("note", "")
+        # the HBM-bound kernel north_star names: the fused guidance loss (forward + backward of the cross-attention energy), live in this run
+        hbm_kernels = None
+        if loss_events:
+            us = sorted(a.elapsed_time(b) * 1e3 for a, b, _ in loss_events)
+            med_us = us[len(us) // 2]
+            nbytes = loss_events[0][2]
+            hbm_kernels = {"guidance_loss": {
+                "what": "csrc/guidance_loss.hip: probabilities of the object tokens + exact top-k selection + dQ for all six guidance keys, "
+                        "3 launches per iteration, no attention map or autograd graph materialised",
+                "us_per_iteration": round(med_us, 1), "launch_sets_timed": len(us), "algorithmic_bytes": nbytes,
+                "algorithmic_bytes_is": "read Q + write dQ of the six keyed layers (BASELINE.md: ~177 MB)",
+                "GB_per_s": round(nbytes / med_us / 1e3, 1), "peak_GB_per_s": 8000.0, "frac": round(nbytes / med_us / 1e3 / 8000.0, 4),
+                "source": "HIP events on the launch stream around the three launches, median over the timed steps of THIS run; rocprofv3 per-kernel "
+                          "durations of the same kernels: profiles/r06_guidance_loss.txt",
+                "share_of_step": round(med_us * 1e-3 / ms_guided, 5)}}
         roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsource if traffic else None, "traffic_note": tnote,
                 "launches": n, "sampled_every": gt.stride,
                 "class_launches_in_timed_region": gt.per_mode.get(dom, 0), "avg_launch_us": round(secs / n * 1e6, 1),
                 "flops_per_launch": round(fl / n / 1e9, 2), "flops_per_launch_unit": "GFLOP",
+                "hbm_kernels": hbm_kernels,
                 "all_gemm": {keyname[m]: {"kernel": names[m], "launches_sampled": v[0], "launches_per_step": round(gt.per_mode.get(m, 0) / args.steps, 1),
                                           "ms_per_step": round(v[1] * 1e3 * gt.stride / args.steps, 2), "tflops": round(v[2] / v[1] / 1e12, 1),
                                           "frac": round(v[2] / v[1] / 1e12 / PEAK_BF16_TFLOPS, 4)} for m, v in agg.items()}}
@@ -458,11 +479,14 @@ def main():
         props = torch.cuda.get_device_properties(dev)
         ident = "|".join(str(getattr(props, k, "")) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
         uid = zlib.crc32(ident.encode())  # stable across processes (str hashes are salted per process): same GPU -> same id
-        mine = torch.tensor([rank, local, uid], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        mine = torch.tensor([rank, local, uid, 1234 + rank, int(latents.float().sum().item() * 1e3)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rccl_seen = {"world_size": dist.get_world_size(), "ranks": sorted(int(t[0]) for t in allr),
-                     "distinct_devices": len({(int(t[1]), int(t[2])) for t in allr}), "backend": backend}
+                     "distinct_devices": len({(int(t[1]), int(t[2])) for t in allr}), "backend": backend,
+                     # every rank works on its own (prompt, seed) sample: the generator seeds and a checksum of each rank's latents
+                     "sample_seeds": [int(t[3]) for t in sorted(allr, key=lambda t: int(t[0]))],
+                     "distinct_samples": len({int(t[4]) for t in allr})}
         from lvd_amd.sharding import gather_frames
         vid = (latents[0, :3].permute(1, 2, 3, 0).clamp(-1, 1).add(1).mul(127.5)).to(torch.uint8)             # (F, h, w, 3)
         vid = vid.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()                                 # (F, 320, 576, 3)
@@ -518,6 +542,9 @@ def main():
                                       "until the first text-dependent layer; that prefix (conv_in, transformer_in, first resnet / temporal conv / spatial self-"
                                       "attention) runs once per sample and is duplicated there.  step_algorithmic_tflop counts it twice, as the reference "
                                       "module does; step_executed_tflop / *_mfma_frac_executed count it once; LVD_CFG_SHARED_PREFIX=0 disables it",
+            "c_abi_calls_per_guided_step": round(abi_calls_per_step, 1),
+            "c_abi_calls_note": "entries into liblvdhip.so per guided step (one entry = one to three kernel launches; the rocprofv3 dispatch count per "
+                                "step is in profiles/r06_bench_summary.txt)",
             "gemm_autotune_table": table_loaded, "rccl_ranks_seen": rccl_seen,
             "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,

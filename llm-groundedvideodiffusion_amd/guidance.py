@@ -126,6 +126,7 @@ class GuidanceLayout:
         return sub
 
 
+loss_kernel_events = None  # measurement hook (bench.py sets a list): (start, end, algorithmic bytes) per fused-loss launch set
 MAX_TOKENS_PER_LAUNCH = 16  # csrc/guidance_loss.hip MAXTOK: object-token columns one launch keeps per query
 
 
@@ -246,9 +247,16 @@ def ca_energy_loss_and_dq_all_keys(items, frames, *, ntext, grad_scale, fg_weigh
         A[i], B[i], Cq[i] = a, b, c
         keeps.append(keep)
     st = torch.cuda.current_stream().cuda_stream
+    ev = None
+    if loss_kernel_events is not None:  # bench.py: the three launches of an iteration bracketed by events on the launch stream
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     hip.check(hip.lib().lvdhip_ca_probs_multi(A, n, st), "ca_probs_multi")
     hip.check(hip.lib().lvdhip_ca_select_multi(B, n, st), "ca_select_multi")
     hip.check(hip.lib().lvdhip_ca_dq_multi(Cq, n, st), "ca_dq_multi")
+    if ev is not None:
+        ev[1].record()
+        loss_kernel_events.append((ev[0], ev[1], sum(2 * q.shape[0] * q.shape[1] * 2 for q, *_ in items)))  # algorithmic bytes: read Q + write dQ
     return [kp["dq"] for kp in keeps]
 
 
@@ -493,15 +501,20 @@ def hip_latent_backward_guidance_many(scheduler, unet, text, index, bboxes_list,
         for i, v in enumerate(active):
             latents_list[v] = ops.axpy_(lat[i:i + 1].contiguous().clone(), grad[i:i + 1].contiguous(), scale)
             loss_list[v] = losses[i]
-            if not more:  # last iteration: hand the value to the next step's entry check through pinned memory (no stall here)
-                pinned = torch.empty(1, dtype=torch.float32, pin_memory=True)
-                pinned.copy_(losses[i].reshape(1), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                losses[i]._host_copy = (pinned, ev)
-        if more:
+        # the V losses reach the host together: ONE pinned copy and ONE event (last iteration: read by the next step's entry check, no stall
+        # here), or one synchronous read when the loop condition needs them now
+        stacked = torch.stack([l.reshape(()) for l in losses])
+        if not more:
+            pinned = torch.empty(len(active), dtype=torch.float32, pin_memory=True)
+            pinned.copy_(stacked, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            for i in range(len(active)):
+                losses[i]._host_copy = (pinned[i:i + 1], ev)
+        else:
+            host_vals = stacked.tolist()
             for i, v in enumerate(active):
-                vals[v] = float(losses[i].item())
+                vals[v] = float(host_vals[i])
                 if math.isnan(vals[v]):
                     print("**Loss is NaN**")
                 if verbose:

@@ -241,7 +241,12 @@ def lib():
     return _lib
 
 
+calls = 0  # C-ABI entries made by this process (bench.py reports them per step; one entry is one to three kernel launches)
+
+
 def check(rc, what):
+    global calls
+    calls += 1
     if rc != 0:
         msg = lib().lvdhip_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"lvdhip {what} failed (rc={rc}): {msg}")

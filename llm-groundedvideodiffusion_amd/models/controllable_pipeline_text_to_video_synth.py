@@ -209,7 +209,11 @@ class TextToVideoSDPipeline:
         if V > 1 and backward_guidance is hip_latent_backward_guidance and not return_guidance_saved_attn and guidance_type == "main" \
                 and all(st["bg_kwargs"] is not None and st["guidance_callback"] is None for st in states):
             hps = [{k: v for k, v in st["bg_kwargs"].items() if k not in ("bboxes", "object_positions")} for st in states]
-            if all(h == hps[0] for h in hps[1:]):
+            try:  # a tensor / ndarray among the values makes `==` ambiguous: such batches keep the one-by-one loop
+                same = all(bool(h == hps[0]) for h in hps[1:])
+            except (ValueError, RuntimeError, TypeError):
+                same = False
+            if same:
                 shared_hp = hps[0]
                 text_cond_all = engine.encode_text(torch.cat([st["prompt_embeds"][1:2] for st in states]))
         for i, t in enumerate(timesteps):
@@ -217,6 +221,8 @@ class TextToVideoSDPipeline:
             if i == num_grounding_steps:
                 self.enable_fuser(False)
             if shared_hp is not None:
+                for st in states:
+                    assert st["latents"].shape[1] == 4, f"latent channel mismatch: {st['latents'].shape}"
                 lats, losses = hip_latent_backward_guidance_many(self.scheduler, self.unet, text_cond_all, i, [st["bg_kwargs"]["bboxes"] for st in states],
                                                                  [st["bg_kwargs"]["object_positions"] for st in states], t,
                                                                  [st["latents"] for st in states], [st["loss_attn"] for st in states], **shared_hp)

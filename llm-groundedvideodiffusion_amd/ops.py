@@ -95,7 +95,8 @@ def _splitk_workspace(dev, nbytes):
     if ws is None:
         ws = _splitk_ws[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev)
     return ws
-_debug_ws = None  # developer probes (tools/stream_trace.py): a tensor handed to every launch as p.ws whatever the product's own need
+_debug_ws = None  # developer probes (tools/stream_trace.py): a tensor handed to every launch as p.ws whatever the product's own need ...
+_DEBUG_HOOKS = os.environ.get("LVD_DEBUG_HOOKS") == "1"  # ... and only when the process was started with LVD_DEBUG_HOOKS=1
 _gemm_choice = {}
 _autotune = {"enabled": True, "min_flops": 2e9}
 _EXCLUDE = tuple(int(v) for v in os.environ.get("LVD_GEMM_EXCLUDE", "").split(",") if v)  # developer knob: variants the tuner must not try
@@ -141,8 +142,11 @@ def _tune_gemm(p, key, out):
     halo = (p.mode == A_CONV3X3 and p.stride == 1 and p.win <= 87) or (p.mode == A_TCONV3 and 2 <= p.frames <= 256)
     if halo and not p.a2 and p.cin % 32 == 0:
         cands += (HALO_VARIANTS if p.ws else HALO_VARIANTS[:1])  # LDS-resident im2col (conv_halo.hip)
+    # the persistent walker (gemm_stream.hip) takes plain-loader products only; anything else would silently run the one-shot ring under its
+    # number (timed twice, and possibly pinned in a saved table for a product that never reaches the walker)
+    stream_ok = p.mode == A_PLAIN and not p.a2 and not p.rowbias and not p.accumulate and not p.out_fp32 and p.K % 32 == 0 and p.K >= 128
     for v in cands:
-        if v in _EXCLUDE:
+        if v in _EXCLUDE or (v == 161 and not stream_ok):
             continue
         p.variant = v
         try:
@@ -212,12 +216,13 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
     if ln_stats is not None:
         assert mode == A_PLAIN and a2 is None and ln_stats.shape == (m, 2) and ln_colsum.shape == (N,)
         p.ln_mean_rstd, p.ln_colsum = _p(ln_stats), _p(ln_colsum)
+    p.ksplit = ksplit  # 0: the library's plan (K-split variants only); set before the workspace query, which depends on it
     need = C.c_int64(0)
     hip.check(hip.lib().lvdhip_gemm_workspace_bytes(C.byref(p), C.byref(need)), "gemm_workspace_bytes")
     if need.value:
         ws = _splitk_workspace(a1.device, need.value)  # one fixed-size buffer per device, shared by all launches of the stream
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    if _debug_ws is not None:
+    if _debug_ws is not None and _DEBUG_HOOKS:
         p.ws, p.ws_bytes = _debug_ws.data_ptr(), _debug_ws.numel() * 4
     if variant == 0 and m_begin == 0 and _autotune["enabled"] and 2.0 * m * N * K >= _autotune["min_flops"]:
         # everything a candidate's eligibility or cost depends on: the conv image (the LDS-resident tap GEMM needs W <= 87), the temporal
@@ -228,7 +233,6 @@ def gemm(a1, w, *, n=None, k=None, a2=None, bias=None, rowbias=None, rows_per_sa
         if variant == 0 and not torch.cuda.is_current_stream_capturing():  # a capture replays what a warm-up run has tuned
             variant = _tune_gemm(p, key, out)
     p.variant = variant
-    p.ksplit = ksplit  # 0: the library's plan (K-split variants only)
     _launch_gemm(p)
     return out
 

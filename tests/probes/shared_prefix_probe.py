@@ -1,5 +1,6 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, lvd_amd
 from lvd_amd.engine import HipUNet3D
 from lvd_amd.weights import TINY, UNetConfig, synthetic_state_dict

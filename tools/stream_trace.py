@@ -25,7 +25,7 @@ for (M, N, K, geglu, hasres, ln) in [(138240, 960, 320, 0, 0, 1), (138240, 960, 
         kw["ln_stats"] = ops.layernorm_stats(a)
         kw["ln_colsum"] = w.float().sum(1).contiguous()
     ws = torch.zeros(1 << 16, device=dev)
-    ops._debug_ws = ws
+    ops._debug_ws, ops._DEBUG_HOOKS = ws, True
     ops.gemm(a, w, variant=161, **kw)
     ws.zero_()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
