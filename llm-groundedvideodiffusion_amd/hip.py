@@ -208,7 +208,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 105
+ABI_VERSION = 106
 CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 

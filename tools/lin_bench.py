@@ -13,6 +13,7 @@ from lvd_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--variants", default="5,105,9,109,17,117,111,131,125")
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--deep", action="store_true", help="the deep-level products (M <= 8640) of a guided step")
 ap.add_argument("--ln", action="store_true", help="the LayerNorm-folded products of the step (to_qkv / to_q / ff.net.0) instead of the plain ones")
 args = ap.parse_args()
 variants = [int(v) for v in args.variants.split(",")]
@@ -24,6 +25,11 @@ shapes = [(138240, 2560, 320, 1, 0), (138240, 320, 320, 0, 1), (4320, 1280, 1280
           (4320, 1280, 10240, 0, 1), (1080, 1280, 1280, 0, 1)]
 
 
+if args.deep:
+    shapes = [(1080, 3840, 1280, 0, 0), (1080, 1280, 1280, 0, 0), (1080, 1280, 1280, 0, 1), (2160, 3840, 1280, 0, 0), (2160, 1280, 1280, 0, 1),
+              (2160, 1280, 2560, 0, 0), (4320, 1280, 1280, 0, 0), (4320, 1280, 1280, 0, 1), (4320, 3840, 1280, 0, 0), (4320, 1280, 3840, 0, 0),
+              (4320, 1280, 5120, 0, 1), (8640, 1280, 1280, 0, 1), (8640, 3840, 1280, 0, 0), (1080, 1280, 5120, 0, 1), (2160, 1280, 5120, 0, 1),
+              (4320, 3840, 1280, 0, 2), (4320, 1280, 1280, 0, 2), (1080, 3840, 1280, 0, 2), (17280, 640, 640, 0, 0), (17280, 640, 640, 0, 1)]
 if args.ln:  # (M, N, K, geglu, "ln")
     shapes = [(138240, 960, 320, 0, 2), (138240, 2560, 320, 1, 2), (34560, 1920, 640, 0, 2), (34560, 5120, 640, 1, 2), (8640, 3840, 1280, 0, 2),
               (69120, 960, 320, 0, 2), (138240, 320, 320, 0, 2)]
