@@ -433,7 +433,7 @@ def main():
         dom = max(agg, key=lambda m: agg[m][1])
         n, secs, fl = agg[dom]
         ach = fl / secs / 1e12
-        tfile = next((f for f in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_gemm_traffic.json")
+        tfile = next((f for f in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_gemm_traffic.json")
         traffic, tnote = None, f"no profiles/{tfile} next to bench.py"
         tpath = os.path.join(ROOT, "profiles", tfile)
         tsource = f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter passes: tools/traffic_passes.sh; NOT measured in this run)"

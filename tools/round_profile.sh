@@ -1,21 +1,21 @@
 # Round-end profile set (run on the GPU box: gpurun -- 'bash tools/round_profile.sh'); everything lands in gpurun_out/, the summaries that
-# are judged are copied to profiles/ by hand afterwards.  ROUND tag: r05.
+# are judged are copied to profiles/ by hand afterwards.  ROUND tag: r06.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-T=r05
+T=r06
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.log 2>&1; tail -1 $O/${T}_smoke.log
 timeout 600 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
-rm -rf $O/prof_r5; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_r5 -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/${T}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof_r5.err)
-python tools/rocprof_rollup.py $O/prof_r5 70 0.5 > $O/${T}_bench_summary.txt 2>&1
-cp $(find $O/prof_r5 -name "*kernel_stats.csv" | head -1) $O/${T}_bench_kernel_stats.csv 2>/dev/null
-find $O/prof_r5 -name "*kernel_trace.csv" -delete; find $O/prof_r5 -name "*.db" -delete
+rm -rf $O/prof_r6; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_r6 -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/${T}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof_r6.err)
+python tools/rocprof_rollup.py $O/prof_r6 70 0.5 > $O/${T}_bench_summary.txt 2>&1
+cp $(find $O/prof_r6 -name "*kernel_stats.csv" | head -1) $O/${T}_bench_kernel_stats.csv 2>/dev/null
+find $O/prof_r6 -name "*kernel_trace.csv" -delete; find $O/prof_r6 -name "*.db" -delete
 # MFMA utilisation of the step's own GEMM variants (the shipped autotune table is loaded by tools/gemm_pmc.py)
-rm -rf $O/pmc_r5; (cd /tmp && timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_r5 -- python $GRAFT_REPO_ROOT/tools/gemm_pmc.py > $GRAFT_REPO_ROOT/$O/pmc_r5.log 2>&1)
-python tools/pmc_rollup.py $(find $O/pmc_r5 -name "*counter_collection.csv" | head -1) > $O/${T}_pmc_mfma_util.txt 2>&1
-find $O/pmc_r5 -name "*.csv" -size +20M -delete
+rm -rf $O/pmc_r6; (cd /tmp && timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_r6 -- python $GRAFT_REPO_ROOT/tools/gemm_pmc.py > $GRAFT_REPO_ROOT/$O/pmc_r6.log 2>&1)
+python tools/pmc_rollup.py $(find $O/pmc_r6 -name "*counter_collection.csv" | head -1) > $O/${T}_pmc_mfma_util.txt 2>&1
+find $O/pmc_r6 -name "*.csv" -size +20M -delete
 # HBM traffic of the GEMM classes (separate FETCH_SIZE / WRITE_SIZE passes)
-ROUND=r05 bash tools/traffic_passes.sh > $O/${T}_traffic_passes.log 2>&1
+ROUND=r06 bash tools/traffic_passes.sh > $O/${T}_traffic_passes.log 2>&1
 # the memory-bound kernels: microseconds and TB/s per level, the guidance loss, the short-K quantisation probe
 timeout 300 python tools/small_ops_bench.py > $O/${T}_hbm_kernels.txt 2>&1
 timeout 200 python tools/loss_bench.py > $O/${T}_guidance_loss.txt 2>&1
@@ -35,7 +35,7 @@ timeout 400 python bench.py --gligen --no-cpu-baseline --steps 10 --warmup 1 > $
 LVD_CFG_SHARED_PREFIX=0 timeout 400 python bench.py --no-cpu-baseline --steps 10 --warmup 1 > $O/${T}_bench_no_shared_prefix.json 2> $O/${T}_bench_no_shared_prefix.err
 python - <<'PY'
 import json
-for f in ("r05_bench", "r05_bench_under_rocprof", "r05_bench_2videos", "r05_bench_2videos_one_by_one", "r05_bench_gligen", "r05_bench_no_shared_prefix"):
+for f in ("r06_bench", "r06_bench_under_rocprof", "r06_bench_2videos", "r06_bench_2videos_one_by_one", "r06_bench_gligen", "r06_bench_no_shared_prefix"):
     try:
         j = json.load(open(f"gpurun_out/{f}.json"))
         print(f, j["value"], j["ms_per_step"], j.get("unguided_ms_per_step"), j.get("step_mfma_frac"), {k: (v["ms_per_step"], v["frac"]) for k, v in j["roofline"]["all_gemm"].items()})
