@@ -101,6 +101,31 @@ def test_gemm_geglu():
     close(ops.geglu_bwd(pre, dy), pre32.grad, 8e-3, "geglu_bwd kernel")
 
 
+def test_geglu_epilogue_gelu_accuracy():
+    """The GEGLU epilogues evaluate GELU as a packed-fp32 polynomial (csrc/common.h gelu_pk2: Phi(x) = 1/2 + x Q(x^2), degree-8 Q on |x| <= 4.25,
+    tools/gelu_fit.py): |gelu - exact| <= 3.7e-5 inside the interval, <= 5e-5 out to |x| = 12.  Seen through the C ABI: gate = a sweep of
+    bf16-exact values, hidden = 1 (bias only), so the output is bf16(gelu(gate)); what is left after the output rounding (2^-9 relative) is
+    the polynomial's error — visible in the negative tail, where gelu itself is tiny."""
+    from lvd_amd.weights import interleave_geglu
+    M, K, inner = 4096, 64, 64
+    x = torch.linspace(-12, 12, M * inner).bfloat16().float().reshape(M, inner)   # bf16-exact gate values
+    a = torch.zeros(M, K)
+    a[:, :inner] = x
+    w = torch.zeros(2 * inner, K)
+    w[inner:, :inner] = torch.eye(inner)    # gate_j = a_j
+    b = torch.zeros(2 * inner)
+    b[:inner] = 1.0                         # hidden = 1
+    wi, bi = interleave_geglu(bf(w).to(DEV), b.to(DEV))
+    out = ops.gemm(bf(a).to(DEV), wi, bias=bi, act=ops.ACT_GEGLU).float().cpu()
+    exact = (x.double() * 0.5 * (1 + torch.erf(x.double() / 2 ** 0.5)))
+    err = (out.double() - exact).abs()
+    bound = 2.0 ** -8 * exact.abs() + 6e-5
+    worst = float((err - bound).max())
+    print("GEGLU epilogue GELU: max |err| in the negative tail (x < -3):", float(err[x < -3].max()), " overall excess over the bf16 bound:", worst)
+    assert worst <= 0, worst
+    assert float(err[x < -3].max()) < 6e-5
+
+
 def conv_w(cout, cin, seed):
     return rnd(cout, cin, 3, 3, seed=seed, scale=0.05)
 
