@@ -271,6 +271,47 @@ def test_guidance_step_vs_reference_golden():
         assert rel(d, d_ref) < 0.07  # 1.5 x the bf16-storage noise floor of this topology (4.5 %, tests/test_noise_floor.py)
 
 
+def test_guidance_step_with_the_ce_energy_vs_oracle_loop():
+    """`hip_latent_backward_guidance(..., use_max_based_loss=False, use_ce_based_loss=True)` — the CE / NLL form of the top-k energy
+    (utils/guidance.py:363-399, selected by the elif chain of :312,346,363) — through the whole guidance step on the tiny topology: recorded
+    forward, fused loss in its CE form, hand-written backward, latent update, against the oracle's forward + compute_ca_loss + autograd with
+    the same options (the oracle's CE restatement is pinned by the reference goldens loss_ce / loss_ce_com).  No form selected raises the
+    reference's ValueError."""
+    from oracle import unet_ref
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=0)
+    net = HipUNet3D(cfg, sd)
+    gen = torch.Generator().manual_seed(21)
+    lat0 = torch.randn(1, 4, 4, 16, 16, generator=gen)
+    cond = torch.randn(1, 77, cfg.cross_attention_dim, generator=gen)
+    keys = [("down", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 1, 0)]
+    boxes, pos = [[[0.1 + 0.05 * f, 0.2, 0.6 + 0.05 * f, 0.8] for f in range(4)], [[0.5, 0.5, 1.0, 1.0]] * 3 + [[0.0] * 4]], [[2], [5, 6]]
+    hp = dict(loss_scale=5.0, loss_threshold=0.01, max_index_step=10, fg_top_p=0.4, bg_top_p=0.3, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03,
+              use_max_based_loss=False, use_ce_based_loss=True, guidance_attn_keys=keys)
+    sched = scheduler_ref.DPMSolverPP2M()
+
+    def unet_fn(x, tt, c, save, save_keys):
+        unet_ref.unet_forward(sd, cfg, x, int(tt), c, save_attn_to_dict=save, save_keys=save_keys, stop_after_key=keys[-1])
+
+    ref_lat, ref_loss = guidance_ref.latent_backward_guidance(unet_fn, sched.alphas_cumprod, cond, 0, boxes, pos, 801, lat0.clone(), 10000.0,
+                                                              max_iter=1, base_attn_dim=(16, 16), **hp)
+    lat, loss = guidance.hip_latent_backward_guidance(sched, net, cond.to(DEV), 0, boxes, pos, 801, lat0.clone().to(DEV), torch.tensor(10000.0),
+                                                      max_iter=1, **hp)
+    d, d_ref = lat.cpu() - lat0, ref_lat - lat0
+    print(f"CE energy: loss {float(loss):.4f} vs oracle {ref_loss:.4f}; update rel-L2 {rel(d, d_ref):.4f}")
+    assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
+    # bf16-storage floor of exactly this problem (oracle/bf16_storage.py, fp32 oracle vs the same oracle with bf16-rounded stores): 5.35e-2 for the
+    # CE form (3.85e-2 for the max-based energy on the same layout: -log a sends 1 / a into the gradient); measured here 8.2e-2 = 1.5 x the floor.
+    # Bound = 2 x floor, the single-realisation bound of test_guidance_update_within_bf16_noise_floor.
+    assert rel(d, d_ref) < 0.107
+    plain, _ = guidance.hip_latent_backward_guidance(sched, net, cond.to(DEV), 0, boxes, pos, 801, lat0.clone().to(DEV), torch.tensor(10000.0), max_iter=1,
+                                                     **{k: v for k, v in hp.items() if not k.startswith("use_")})
+    assert rel(plain.cpu() - lat0, d_ref) > 3 * rel(d, d_ref)  # the max-based energy is another function: the option is not ignored
+    with pytest.raises(ValueError, match="no loss selected"):
+        guidance.hip_latent_backward_guidance(sched, net, cond.to(DEV), 0, boxes, pos, 801, lat0.clone().to(DEV), torch.tensor(10000.0), max_iter=1,
+                                              **dict(hp, use_ce_based_loss=False))
+
+
 @pytest.mark.parametrize("t,layout", [(801, "2obj"), (801, "1box"), (999, "1box")])
 def test_guidance_update_within_bf16_noise_floor(t, layout):
     """The tolerance of the guidance update is not free-standing.  The fp32 oracle run with bf16 STORAGE of activations and activation
