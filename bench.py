@@ -543,8 +543,8 @@ def main():
                                       "attention) runs once per sample and is duplicated there.  step_algorithmic_tflop counts it twice, as the reference "
                                       "module does; step_executed_tflop / *_mfma_frac_executed count it once; LVD_CFG_SHARED_PREFIX=0 disables it",
             "c_abi_calls_per_guided_step": round(abi_calls_per_step, 1),
-            "c_abi_calls_note": "entries into liblvdhip.so per guided step (one entry = one to three kernel launches; the rocprofv3 dispatch count per "
-                                "step is in profiles/r06_bench_summary.txt)",
+            "c_abi_calls_note": "launching entries into liblvdhip.so per guided step (one entry = one to three kernels); rocprofv3 counts 2790 dispatches per guided and "
+                                "1043 per unguided step (profiles/r06_bench_summary.txt)",
             "gemm_autotune_table": table_loaded, "rccl_ranks_seen": rccl_seen,
             "frame_gather_ms_untimed": None if gather_ms is None else round(gather_ms, 2),
             "roofline": roof, "cpu_baseline": cpu,

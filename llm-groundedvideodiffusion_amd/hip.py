@@ -241,12 +241,12 @@ def lib():
     return _lib
 
 
-calls = 0  # C-ABI entries made by this process (bench.py reports them per step; one entry is one to three kernel launches)
+calls = 0  # launching C-ABI entries made by this process (bench.py reports them per step; one entry is one to three kernel launches)
 
 
 def check(rc, what):
     global calls
-    calls += 1
+    calls += what != "gemm_workspace_bytes"  # a size query launches nothing
     if rc != 0:
         msg = lib().lvdhip_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"lvdhip {what} failed (rc={rc}): {msg}")

@@ -27,6 +27,17 @@ def main():
         import csv
         path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
         rows = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(path))), key=lambda r: r[1])
+    # dispatches per denoising step: a step ends with its fused CFG / DPM-Solver++ update (one cfg_dpm_step launch); it is a guided step when
+    # it holds the guidance-loss launches (ca_probs*).  Counted over the whole trace, before the leading fraction is dropped.
+    guided, unguided, cur, has_loss = [], [], 0, False
+    for n, s, e in rows:
+        cur += 1
+        has_loss = has_loss or "ca_probs" in n
+        if "cfg_dpm_step" in n:
+            (guided if has_loss else unguided).append(cur)
+            cur, has_loss = 0, False
+    med = lambda v: sorted(v)[len(v) // 2] if v else 0
+    per_step = f"# dispatches per step (median over {len(guided)} guided / {len(unguided)} unguided steps of the trace): guided {med(guided)}, unguided {med(unguided)}"
     rows = rows[int(len(rows) * skip):]
     agg = collections.defaultdict(lambda: [0, 0])
     for n, s, e in rows:
@@ -36,6 +47,7 @@ def main():
     tot = sum(a[1] for a in agg.values())
     wall = rows[-1][2] - rows[0][1]
     print(f"# {len(rows)} dispatches, {tot / 1e6:.1f} ms of kernel time in {wall / 1e6:.1f} ms of wall time")
+    print(per_step)
     cls = collections.OrderedDict((c[0], [0, 0]) for c in CLASSES)
     cls["torch housekeeping (fills, copies)"] = [0, 0]
     for n, (c, t) in agg.items():
