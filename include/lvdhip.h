@@ -377,6 +377,23 @@ int lvdhip_ca_probs_multi(const lvd_ca_probs_params* keys, int32_t nkeys, void* 
 int lvdhip_ca_select_multi(const lvd_ca_select_params* keys, int32_t nkeys, void* stream);
 int lvdhip_ca_dq_multi(const lvd_ca_dq_params* keys, int32_t nkeys, void* stream);
 
+/* Map-level options of add_ca_loss_per_attn_map_to_loss (utils/guidance.py:209-226), on WHOLE maps — fp32 [rows = frames * heads, P, T] as
+ * lvdhip_ca_probs_full writes them — because both spread the energy's gradient over text tokens that are not object tokens:
+ *   smooth_attn  (:209-220): F.pad(map, (1,1,1,1), "reflect") then a 3x3 Gaussian (utils/attn.py GaussianSmoothing, kernel 3, sigma 0.5) over the
+ *                (position, token) plane of every (frame, head): lvdhip_ca_map_smooth with w9 = the normalised kernel, row-major [position tap][token tap];
+ *                adjoint = 1 applies the transpose of that linear map (the backward);
+ *   attn_renorm  (:222-226): softmax over tokens [tok_lo, tok_lo + tok_n) = [1, num_tokens - 1) of renorm_scale * map; the output's column u is
+ *                token tok_lo + u (columns from tok_n on are written as 0); backward = 1 takes the gradient w.r.t. that output (same layout) and
+ *                writes the gradient w.r.t. the input map (0 outside the token range);
+ *   gather / scatter: the object-token columns in the [frames, heads, ntok, P] layout lvdhip_ca_select reads, and their gradient back into a map;
+ *   softmax_bwd: dS = scale * A o (dA - rowsum(A o dA)), the backward of softmax(scale * Q K^T); dQ = lvdhip_ca_apply_probs(dS, K). */
+int lvdhip_ca_map_smooth(const float* in, float* out, int64_t rows, int32_t P, int32_t T, const float* w9, int32_t adjoint, void* stream);
+int lvdhip_ca_map_renorm(const float* in, const float* dout, float* out, int64_t rows, int32_t P, int32_t T, int32_t tok_lo, int32_t tok_n,
+                         float renorm_scale, int32_t backward, void* stream);
+int lvdhip_ca_map_gather_cols(const float* map, const int32_t* cols, int32_t ncols, float* out, int64_t rows, int32_t P, int32_t T, void* stream);
+int lvdhip_ca_map_scatter_cols(const float* dcols, const int32_t* cols, int32_t ncols, float* dmap, int64_t rows, int32_t P, int32_t T, void* stream);
+int lvdhip_ca_map_softmax_bwd(const float* probs, const float* dprobs, float* ds, int64_t rows, int32_t P, int32_t T, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Element-wise / layout kernels.
  * ------------------------------------------------------------------------------------------ */

@@ -26,11 +26,15 @@ from .engine import HipUNet3D, Tape, Geom
 
 DEFAULT_GUIDANCE_ATTN_KEYS = [("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0)]  # models/pipelines.py:13-18
 
-# loss options of utils/guidance.py:160-526 that are NOT built (none is reachable from generate.py's command line): they raise
-_UNSUPPORTED = dict(exclude_bg_heads=False, smooth_attn=False, attn_renorm=False, upsample_scale=1)
+# loss options of utils/guidance.py:160-526 that are NOT built: they raise (upsample_scale != 1 raises RuntimeError in the reference's own max-based /
+# CE forms; exclude_bg_heads is an assertion failure there)
+_UNSUPPORTED = dict(exclude_bg_heads=False, upsample_scale=1)
 # optional terms that ARE built into the fused loss kernel (generate.py:78-106, generation/lvd.py:85-106 forward them)
 _LOSS_OPTIONS = ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "com_loss_scale", "use_ratio_based_loss", "attn_sync_weight",
-                 "boxdiff_loss_scale", "boxdiff_normed", "boxdiff_L", "use_max_based_loss", "use_ce_based_loss")
+                 "boxdiff_loss_scale", "boxdiff_normed", "boxdiff_L", "use_max_based_loss", "use_ce_based_loss",
+                 # map-level options (utils/guidance.py:209-226): whole-map path, csrc/guidance_maps.hip
+                 "smooth_attn", "kernel_size", "sigma", "attn_renorm", "num_tokens", "renorm_scale")
+_MAP_OPTIONS = ("smooth_attn", "kernel_size", "sigma", "attn_renorm", "num_tokens", "renorm_scale")
 
 
 def _energy_form(use_ratio_based_loss, use_max_based_loss, use_ce_based_loss):
@@ -132,11 +136,22 @@ MAX_TOKENS_PER_LAUNCH = 16  # csrc/guidance_loss.hip MAXTOK: object-token column
 
 def ca_energy_loss_and_dq(q, k, heads, frames, layout: GuidanceLayout, *, ntext, grad_scale, fg_weight, bg_weight,
                           com_loss_scale, loss_partial, want_dq=True, use_ratio_based_loss=False, attn_sync_weight=0.0,
-                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, use_max_based_loss=True, use_ce_based_loss=False, _acc=None):
+                          boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, use_max_based_loss=True, use_ce_based_loss=False, _acc=None,
+                          **map_options):
     """One guidance key: q [frames*P, heads*64] bf16, k [ntext, heads*64] bf16 (strided ok).
 
     Writes the per-(frame, head, token) loss terms into ``loss_partial`` [frames*heads*ntok] and returns dQ.  Layouts with
-    more object tokens than one launch holds run in chunks of tokens: the loss terms are per token and dQ is linear in them."""
+    more object tokens than one launch holds run in chunks of tokens: the loss terms are per token and dQ is linear in them.
+    `smooth_attn` / `attn_renorm` (and their parameters) take the whole-map path, ca_energy_loss_and_dq_maps."""
+    unknown = set(map_options) - set(_MAP_OPTIONS)
+    if unknown:
+        raise TypeError(f"ca_energy_loss_and_dq: unexpected options {sorted(unknown)}")
+    if map_options.get("smooth_attn") or map_options.get("attn_renorm"):
+        assert _acc is None and want_dq
+        return ca_energy_loss_and_dq_maps(q, k, heads, frames, layout, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                          com_loss_scale=com_loss_scale, loss_partial=loss_partial, use_ratio_based_loss=use_ratio_based_loss,
+                                          attn_sync_weight=attn_sync_weight, boxdiff_loss_scale=boxdiff_loss_scale, boxdiff_normed=boxdiff_normed,
+                                          boxdiff_L=boxdiff_L, use_max_based_loss=use_max_based_loss, use_ce_based_loss=use_ce_based_loss, **map_options)
     if layout.ntok and int(layout.tok_ids_host.max()) >= ntext:  # the reference indexes attn[..., pos] and raises the same way
         raise IndexError(f"object token position {int(layout.tok_ids_host.max())} is out of bounds for {ntext} text tokens")
     if layout.ntok > MAX_TOKENS_PER_LAUNCH and _acc is None:
@@ -219,11 +234,107 @@ def _ca_params(q, k, heads, frames, layout, *, ntext, grad_scale, fg_weight, bg_
     return a, b, c, keep
 
 
+def gaussian_kernel_3x3(sigma):
+    """utils/attn.py GaussianSmoothing(kernel_size=3, sigma): per dimension 1 / (s sqrt(2 pi)) * exp(-((x - mean) / (2 s))^2) — the reference's
+    own exponent, not the textbook one —, outer product, normalised to sum 1; row-major [position tap][token tap]."""
+    x = torch.arange(3, dtype=torch.float32)
+    g = 1.0 / (sigma * math.sqrt(2 * math.pi)) * torch.exp(-(((x - 1.0) / (2 * sigma)) ** 2))
+    k = g[:, None] * g[None, :]
+    return (k / k.sum()).reshape(9).contiguous()
+
+
+def ca_maps_loss_and_grad(a0, heads, frames, layout: GuidanceLayout, *, grad_scale, fg_weight, bg_weight, com_loss_scale, loss_partial,
+                          smooth_attn=False, kernel_size=3, sigma=0.5, attn_renorm=False, num_tokens=None, renorm_scale=2.0, **term_options):
+    """The energy on WHOLE probability maps a0 [frames, heads, P, T] fp32 with the map-level options of add_ca_loss_per_attn_map_to_loss
+    (utils/guidance.py:209-226): [3x3 Gaussian, reflect-padded] -> [softmax of renorm_scale * tokens 1 .. num_tokens-2] -> object columns -> the
+    unchanged selection / loss kernel (loss terms into `loss_partial`), and the same chain backwards.  Returns d(loss)/d(a0), same shape
+    (already scaled by grad_scale like the selection kernel's dA).  csrc/guidance_maps.hip."""
+    dev = a0.device
+    P = layout.H * layout.W
+    rows, T = frames * heads, a0.shape[-1]
+    assert a0.dtype == torch.float32 and a0.is_contiguous() and tuple(a0.shape) == (frames, heads, P, T), a0.shape
+    ops.use_device(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib = hip.lib()
+    m = a0
+    w9 = None
+    if smooth_attn:
+        if int(kernel_size) != 3:  # the reference pads by one position / token whatever the kernel size and asserts the shape is kept
+            raise NotImplementedError(f"smooth_attn with kernel_size={kernel_size}: only the 3x3 kernel keeps the map's shape (utils/guidance.py:213-220)")
+        w9 = gaussian_kernel_3x3(float(sigma)).to(dev)
+        sm = torch.empty_like(m)
+        hip.check(lib.lvdhip_ca_map_smooth(m.data_ptr(), sm.data_ptr(), rows, P, T, w9.data_ptr(), 0, st), "ca_map_smooth")
+        m = sm
+    cols_host = layout.tok_ids_host.astype(np.int64)
+    renorm_in = None
+    limit = T
+    if attn_renorm:
+        if term_options.get("attn_sync_weight", 0.0) != 0.0:
+            raise AssertionError("attn_sync with attn_renorm not implemented together")  # the reference's own assertion, :404-406
+        if num_tokens is None:
+            raise TypeError("attn_renorm needs num_tokens (the reference slices attn_map[..., 1:num_tokens - 1])")
+        limit = int(num_tokens) - 2
+        if limit < 1 or limit + 1 > T:
+            raise IndexError(f"num_tokens={num_tokens} leaves no token range inside the map's {T} text positions")
+        cols_host = cols_host - 1  # "Since we removed SOT, we subtract 1 from obj_position", :291-294
+        rn = torch.empty_like(m)
+        hip.check(lib.lvdhip_ca_map_renorm(m.data_ptr(), None, rn.data_ptr(), rows, P, T, 1, limit, float(renorm_scale), 0, st), "ca_map_renorm")
+        renorm_in, m = m, rn
+    if layout.ntok and (int(cols_host.min()) < 0 or int(cols_host.max()) >= limit):  # the reference indexes attn_map[..., pos]
+        raise IndexError(f"object token position {int(layout.tok_ids_host.max())} is out of bounds for the {limit} tokens of the map")
+    cols = torch.from_numpy(cols_host.astype(np.int32)).to(dev)
+    probs = torch.empty((frames, heads, layout.ntok, P), dtype=torch.float32, device=dev)
+    dprobs = torch.empty_like(probs)
+    com_ws = torch.empty((frames, heads, layout.ntok, 4), dtype=torch.float32, device=dev)
+    b = hip.CaSelectParams()
+    b.probs, b.dprobs = probs.data_ptr(), dprobs.data_ptr()
+    b.frames, b.heads, b.P, b.ntok, b.H, b.W = frames, heads, P, layout.ntok, layout.H, layout.W
+    b.tok_obj, b.boxes, b.tok_weight, b.nobj = layout.tok_obj.data_ptr(), layout.boxes.data_ptr(), layout.tok_weight.data_ptr(), layout.nobj
+    b.fg_weight, b.bg_weight, b.com_loss_scale, b.grad_scale = fg_weight, bg_weight, com_loss_scale, grad_scale
+    b.loss_partial, b.com_ws = loss_partial.data_ptr(), com_ws.data_ptr()
+    b.use_ratio_loss = _energy_form(term_options.get("use_ratio_based_loss", False), term_options.get("use_max_based_loss", True),
+                                    term_options.get("use_ce_based_loss", False))
+    b.ratio_eps, b.attn_sync_weight = 1.0e-2, float(term_options.get("attn_sync_weight", 0.0))
+    b.boxdiff_loss_scale, b.boxdiff_normed, b.boxdiff_L = (float(term_options.get("boxdiff_loss_scale", 0.0)), int(bool(term_options.get("boxdiff_normed", True))),
+                                                           int(term_options.get("boxdiff_L", 1)))
+    hip.check(lib.lvdhip_ca_map_gather_cols(m.data_ptr(), cols.data_ptr(), layout.ntok, probs.data_ptr(), rows, P, T, st), "ca_map_gather_cols")
+    hip.check(lib.lvdhip_ca_select(C.byref(b), st), "ca_select")
+    dm = torch.empty_like(a0)
+    hip.check(lib.lvdhip_ca_map_scatter_cols(dprobs.data_ptr(), cols.data_ptr(), layout.ntok, dm.data_ptr(), rows, P, T, st), "ca_map_scatter_cols")
+    if attn_renorm:
+        back = torch.empty_like(a0)
+        hip.check(lib.lvdhip_ca_map_renorm(renorm_in.data_ptr(), dm.data_ptr(), back.data_ptr(), rows, P, T, 1, limit, float(renorm_scale), 1, st), "ca_map_renorm")
+        dm = back
+    if smooth_attn:
+        back = torch.empty_like(a0)
+        hip.check(lib.lvdhip_ca_map_smooth(dm.data_ptr(), back.data_ptr(), rows, P, T, w9.data_ptr(), 1, st), "ca_map_smooth")
+        dm = back
+    return dm
+
+
+def ca_energy_loss_and_dq_maps(q, k, heads, frames, layout: GuidanceLayout, *, ntext, dq_out=None, **options):
+    """One guidance key with `smooth_attn` and / or `attn_renorm`: probabilities of ALL text positions (lvdhip_ca_probs_full), the map chain of
+    ca_maps_loss_and_grad, the softmax backward on the whole map and dQ = dS . K (lvdhip_ca_apply_probs).  Same contract as ca_energy_loss_and_dq
+    (loss terms into `loss_partial`, returns dQ).  Not a fast path: no entry point of the reference switches these options on."""
+    P = layout.H * layout.W
+    a0 = ca_probability_maps(q, k, samples=frames, heads=heads, positions=P, ntext=ntext, samples_per_key=frames)  # [frames, heads, P, T] fp32
+    dm = ca_maps_loss_and_grad(a0, heads, frames, layout, **options)
+    ds = torch.empty_like(a0)
+    hip.check(hip.lib().lvdhip_ca_map_softmax_bwd(a0.data_ptr(), dm.data_ptr(), ds.data_ptr(), frames * heads, P, ntext, 0.125,
+                                                  torch.cuda.current_stream().cuda_stream), "ca_map_softmax_bwd")
+    return ca_apply_probabilities(ds, k, samples=frames, heads=heads, positions=P, ntext=ntext, samples_per_key=frames, out=dq_out)
+
+
 def ca_energy_loss_and_dq_all_keys(items, frames, *, ntext, grad_scale, fg_weight, bg_weight, com_loss_scale, **loss_options):
     """Every key of a guidance iteration in ONE launch per stage (probabilities / selection + loss / dQ: 3 launches instead of 3 per key;
     csrc/guidance_loss.hip *_multi).  `items`: (q, k, heads, layout, loss_partial slice[, dq rows to write]) per key.  Same bits as the
     key-by-key calls.  Layouts with more object tokens than a launch holds (chunked dQ accumulation) take the key-by-key path."""
     items = [it if len(it) == 6 else (*it, None) for it in items]
+    map_opts = {o: loss_options.pop(o) for o in _MAP_OPTIONS if o in loss_options}
+    if map_opts.get("smooth_attn") or map_opts.get("attn_renorm"):  # whole-map path, key by key (csrc/guidance_maps.hip)
+        return [ca_energy_loss_and_dq_maps(q, k, heads, frames, lay, ntext=ntext, grad_scale=grad_scale, fg_weight=fg_weight, bg_weight=bg_weight,
+                                           com_loss_scale=com_loss_scale, loss_partial=part, dq_out=dq_out, **map_opts, **loss_options)
+                for q, k, heads, lay, part, dq_out in items]
     if len(items) > hip.CA_MAX_KEYS or any(lay.ntok > MAX_TOKENS_PER_LAUNCH for _, _, _, lay, _, _ in items):
         outs = []
         for q, k, heads, lay, part, dq_out in items:

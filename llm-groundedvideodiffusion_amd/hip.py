@@ -177,6 +177,11 @@ SYMBOLS = {
     "lvdhip_ca_probs": [_P(CaProbsParams), C.c_void_p],
     "lvdhip_ca_probs_full": [_P(CaProbsFullParams), C.c_void_p],
     "lvdhip_ca_apply_probs": [_P(CaApplyProbsParams), C.c_void_p],
+    "lvdhip_ca_map_smooth": [C.c_void_p, C.c_void_p, C.c_int64, i32, i32, C.c_void_p, i32, C.c_void_p],
+    "lvdhip_ca_map_renorm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i32, i32, i32, i32, f32, i32, C.c_void_p],
+    "lvdhip_ca_map_gather_cols": [C.c_void_p, C.c_void_p, i32, C.c_void_p, C.c_int64, i32, i32, C.c_void_p],
+    "lvdhip_ca_map_scatter_cols": [C.c_void_p, C.c_void_p, i32, C.c_void_p, C.c_int64, i32, i32, C.c_void_p],
+    "lvdhip_ca_map_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i32, i32, f32, C.c_void_p],
     "lvdhip_ca_select": [_P(CaSelectParams), C.c_void_p],
     "lvdhip_ca_dq": [_P(CaDqParams), C.c_void_p],
     "lvdhip_ca_probs_multi": [_P(CaProbsParams), i32, C.c_void_p],
@@ -208,7 +213,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 106
+ABI_VERSION = 107
 CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 

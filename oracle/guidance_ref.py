@@ -7,8 +7,8 @@ Follows, on any device and in fp32:
                                       centre-of-mass + velocity terms :468-522, per-object token normalisation :524)
   compute_ca_lossv3                   /root/reference/utils/guidance.py:529-574
   latent_backward_guidance            /root/reference/models/pipelines.py:21-150
-Only the branches the video entry points use are restated (max-based loss, upsample_scale=1, no smoothing /
-renorm / ratio / CE / attn-sync / BoxDiff).  Pinned by tests/golden/guidance_*.npz generated from the shimmed
+Restated: max-based, ratio-based and CE energies, attention sync, BoxDiff, centre of mass, `smooth_attn`, `attn_renorm`;
+not restated: upsample_scale != 1 (the reference's own max-based / CE forms raise on it).  Pinned by tests/golden/guidance_*.npz generated from the shimmed
 reference import (oracle/make_golden.py).
 """
 import math
@@ -35,12 +35,28 @@ def _com(x, h_range, w_range):
 
 def ca_loss_per_map(attn_map, bboxes, object_positions, base_attn_dim, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
                     bg_weight=1.0, com_loss_scale=0.0, use_ratio_based_loss=False, eps=1.0e-2, attn_sync_weight=0.0,
-                    boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, use_max_based_loss=True, use_ce_based_loss=False):
+                    boxdiff_loss_scale=0.0, boxdiff_normed=True, boxdiff_L=1, use_max_based_loss=True, use_ce_based_loss=False,
+                    smooth_attn=False, kernel_size=3, sigma=0.5, attn_renorm=False, num_tokens=None, renorm_scale=2.0):
     """attn_map: (frames, heads, P, tokens) probabilities.  Returns the un-normalised loss contribution.
     utils/guidance.py:160-526 (add_ca_loss_per_attn_map_to_loss) with upsample_scale = 1, no smoothing / renorm / CE:
     max-based top-k energy (default), the deprecated ratio-based energy (:312-323) or the CE / NLL form (:363-399), attention sync between consecutive frames
     (:401-430), BoxDiff corner constraint (:240-287, 433-465), centre-of-mass position / velocity terms (:467-522)."""
     n_f, heads, P, _ = attn_map.shape
+    if smooth_attn:
+        # :209-220 — F.pad(attn_map, (1, 1, 1, 1), "reflect") pads the (position, token) plane of every (frame, head); GaussianSmoothing
+        # (utils/attn.py:88-160, dim=2, channels=heads) is a depthwise conv2d with the normalised outer product of
+        # g[x] = 1 / (s sqrt(2 pi)) * exp(-((x - mean) / (2 s))^2)   (the reference's own exponent)
+        x = torch.arange(kernel_size, dtype=torch.float32, device=attn_map.device)
+        g = 1.0 / (sigma * math.sqrt(2 * math.pi)) * torch.exp(-(((x - (kernel_size - 1) / 2) / (2 * sigma)) ** 2))
+        k2 = g[:, None] * g[None, :]
+        k2 = (k2 / k2.sum()).view(1, 1, kernel_size, kernel_size).repeat(heads, 1, 1, 1)
+        attn_map = torch.nn.functional.conv2d(torch.nn.functional.pad(attn_map, (1, 1, 1, 1), mode="reflect"), k2.to(attn_map.dtype), groups=heads)
+        assert attn_map.shape[:3] == (n_f, heads, P)
+    if attn_renorm:
+        # :222-226 — tokens 1 .. num_tokens-2 (start / end-of-text dropped), scaled, re-normalised; object positions shift by one (:291-294)
+        attn_map = torch.softmax(attn_map[..., 1:num_tokens - 1] * renorm_scale, dim=-1)
+        object_positions = [[p - 1 for p in ps] for ps in object_positions]
+        assert attn_sync_weight == 0.0, "attn_sync with attn_renorm not implemented together"
     H, W = get_hw_from_attn_dim(P, base_attn_dim)
     dev = attn_map.device
     h_range = torch.arange(H, device=dev, dtype=torch.float32)[None]

@@ -225,7 +225,12 @@ def main():
               "all": dict(fg_top_p=0.3, bg_top_p=0.6, fg_weight=1.5, bg_weight=2.5, attn_sync_weight=1.0, boxdiff_loss_scale=0.4, com_loss_scale=0.03),
               # CE / NLL form of the top-k energy (utils/guidance.py:363-399), alone and with the centre-of-mass term
               "ce": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0),
-              "ce_com": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.25, bg_top_p=0.4, fg_weight=1.5, bg_weight=0.5, com_loss_scale=0.03)}
+              "ce_com": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.25, bg_top_p=0.4, fg_weight=1.5, bg_weight=0.5, com_loss_scale=0.03),
+              # map-level options (utils/guidance.py:209-226): 3x3 Gaussian over the (position, token) plane; second softmax over tokens 1 .. num_tokens-2
+              "smooth": dict(smooth_attn=True, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0),
+              "renorm": dict(attn_renorm=True, num_tokens=9, renorm_scale=2.0, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03),
+              "smooth_renorm": dict(smooth_attn=True, attn_renorm=True, num_tokens=8, renorm_scale=3.0, fg_top_p=0.3, bg_top_p=0.4, fg_weight=1.5, bg_weight=1.0,
+                                    boxdiff_loss_scale=0.4)}
     for name, kw in cases2.items():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

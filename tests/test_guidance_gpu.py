@@ -133,7 +133,7 @@ def test_fused_loss_map_sizes_and_prompt_lengths(Hh, Ww, nt):
     assert rel(dq, gq) < 1.5e-2, rel(dq, gq)
 
 
-@pytest.mark.parametrize("case", ["ratio", "sync", "boxdiff", "boxdiff_sum", "all", "ce", "ce_com"])
+@pytest.mark.parametrize("case", ["ratio", "sync", "boxdiff", "boxdiff_sum", "all", "ce", "ce_com", "smooth", "renorm", "smooth_renorm"])
 def test_fused_loss_optional_terms_vs_oracle_and_reference(case):
     """Ratio-based energy, attention sync, BoxDiff corner constraint in the fused kernel: (i) on projected Q/K vs autograd through
     the oracle, (ii) on the reference's own maps: the kernel's loss / dA against the golden loss / gradient of utils/guidance.py."""
@@ -158,6 +158,68 @@ def test_fused_loss_optional_terms_vs_oracle_and_reference(case):
     loss = ops.reduce_sum(partial, gs).item()
     assert abs(loss - ref.item()) < 3e-4 * abs(ref.item()), (case, loss, ref.item())
     assert rel(dq, gq) < 1.5e-2, (case, rel(dq, gq))
+
+
+@pytest.mark.parametrize("case", ["smooth", "renorm", "smooth_renorm"])
+def test_map_level_options_on_the_reference_maps_vs_golden(case):
+    """`smooth_attn` / `attn_renorm` (utils/guidance.py:209-226; csrc/guidance_maps.hip) on the REFERENCE's own probability maps: loss and the
+    gradient w.r.t. both maps against the golden values utils/guidance.py + autograd produced (oracle/make_golden.py section (c)).  fp32 in,
+    fp32 out: the whole chain — reflect-padded 3x3 Gaussian and its adjoint, the second softmax and its backward, column gather / scatter, the
+    unchanged selection kernel — to 2e-5."""
+    from test_oracle import LOSS_VARIANTS
+    g = np.load(os.path.join(G, "guidance_loss.npz"))
+    kw = dict(LOSS_VARIANTS[case])
+    bboxes, pos = g["bboxes2"].tolist(), [[2, 3], [6]]
+    frames, heads, Hh, Ww = 4, 3, 8, 12
+    fg, bgp, com = kw.pop("fg_top_p"), kw.pop("bg_top_p"), kw.pop("com_loss_scale", 0.0)
+    lay = guidance.GuidanceLayout(bboxes, pos, frames, Hh, Ww, fg, bgp, DEV)
+    gs = 1.0 / (len(bboxes) * 2)  # loss_scale 1, two objects, two keys (compute_ca_lossv3's normalisation, utils/guidance.py:569-572)
+    total = 0.0
+    for i in range(2):
+        a0 = torch.from_numpy(g[f"maps_{i}"])[0].to(DEV).contiguous()  # (frames, heads, P, 10 tokens)
+        partial = torch.zeros(frames * heads * 3, device=DEV)
+        dm = guidance.ca_maps_loss_and_grad(a0, heads, frames, lay, grad_scale=gs, com_loss_scale=com, loss_partial=partial, **kw)
+        total += ops.reduce_sum(partial, gs).item()
+        want = torch.from_numpy(g[f"grad{i}_{case}"])[0]
+        assert rel(dm, want) < 2e-5, (case, i, rel(dm, want))
+    assert abs(total - float(g[f"loss_{case}"])) < 2e-5 * abs(float(g[f"loss_{case}"])), (case, total, float(g[f"loss_{case}"]))
+
+
+def test_guidance_step_with_map_level_options_vs_oracle_loop():
+    """`hip_latent_backward_guidance(..., smooth_attn=True, attn_renorm=True, num_tokens=..., renorm_scale=...)` through the whole guidance step on
+    the tiny topology against the oracle's forward + compute_ca_loss + autograd with the same options; out-of-range and missing `num_tokens`
+    raise as the reference's indexing would."""
+    from oracle import unet_ref
+    cfg = UNetConfig(**TINY)
+    sd = synthetic_state_dict(cfg, seed=0)
+    net = HipUNet3D(cfg, sd)
+    gen = torch.Generator().manual_seed(22)
+    lat0 = torch.randn(1, 4, 4, 16, 16, generator=gen)
+    cond = torch.randn(1, 77, cfg.cross_attention_dim, generator=gen)
+    keys = [("down", 1, 0, 0), ("up", 1, 1, 0), ("up", 2, 1, 0)]
+    boxes, pos = [[[0.1 + 0.05 * f, 0.2, 0.6 + 0.05 * f, 0.8] for f in range(4)], [[0.5, 0.5, 1.0, 1.0]] * 3 + [[0.0] * 4]], [[2], [5, 6]]
+    hp = dict(loss_scale=5.0, loss_threshold=0.01, max_index_step=10, fg_top_p=0.4, bg_top_p=0.3, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03,
+              smooth_attn=True, attn_renorm=True, num_tokens=12, renorm_scale=2.0, guidance_attn_keys=keys)
+    sched = scheduler_ref.DPMSolverPP2M()
+
+    def unet_fn(x, tt, c, save, save_keys):
+        unet_ref.unet_forward(sd, cfg, x, int(tt), c, save_attn_to_dict=save, save_keys=save_keys, stop_after_key=keys[-1])
+
+    ref_lat, ref_loss = guidance_ref.latent_backward_guidance(unet_fn, sched.alphas_cumprod, cond, 0, boxes, pos, 801, lat0.clone(), 10000.0,
+                                                              max_iter=1, base_attn_dim=(16, 16), **hp)
+    run = lambda **over: guidance.hip_latent_backward_guidance(sched, net, cond.to(DEV), 0, boxes, pos, 801, lat0.clone().to(DEV), torch.tensor(10000.0),
+                                                               max_iter=1, **dict(hp, **over))
+    lat, loss = run()
+    d, d_ref = lat.cpu() - lat0, ref_lat - lat0
+    print(f"smooth + renorm: loss {float(loss):.4f} vs oracle {ref_loss:.4f}; update rel-L2 {rel(d, d_ref):.4f}")
+    assert abs(float(loss) - ref_loss) < 2e-2 * abs(ref_loss)
+    # the bf16-storage floor of exactly this problem is 0.108 (oracle/bf16_storage.py: the second softmax sharpens the maps, and with them every
+    # rounding of the trunk); single realisations get 2 x the floor, as in test_guidance_update_within_bf16_noise_floor
+    assert rel(d, d_ref) < 0.216
+    with pytest.raises(TypeError, match="num_tokens"):
+        run(num_tokens=None)
+    with pytest.raises(IndexError):
+        run(num_tokens=7)  # tokens 1 .. 5: object position 6 falls outside
 
 
 @pytest.mark.parametrize("com", [0.0, 0.03])

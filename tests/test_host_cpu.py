@@ -163,7 +163,7 @@ def test_guidance_layout_matches_oracle_box_logic():
         assert list(arr[f]) == [x0, y0, x1, y1, kfg, kbg]
     assert lay.tok_ids.tolist() == [2, 5] and lay.tok_weight.tolist() == [0.5, 0.5]
     with pytest.raises(NotImplementedError):
-        guidance.hip_latent_backward_guidance(None, None, None, 0, boxes, [[2]], 1, None, 1.0, smooth_attn=True)  # smoothing / renorm / upsampled-map variants are not built
+        guidance.hip_latent_backward_guidance(None, None, None, 0, boxes, [[2]], 1, None, 1.0, upsample_scale=2)  # the reference's own max-based / CE forms raise on it
     assert [guidance._energy_form(*a) for a in ((False, True, False), (True, True, True), (False, False, True))] == [0, 1, 2]  # the chain of utils/guidance.py:312,346,363
     with pytest.raises(ValueError, match="no loss selected"):
         guidance._energy_form(False, False, False)

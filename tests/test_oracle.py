@@ -81,6 +81,10 @@ LOSS_VARIANTS = {  # the cases of oracle/make_golden.py section (c), second box 
     "all": dict(fg_top_p=0.3, bg_top_p=0.6, fg_weight=1.5, bg_weight=2.5, attn_sync_weight=1.0, boxdiff_loss_scale=0.4, com_loss_scale=0.03),
     "ce": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0),
     "ce_com": dict(use_max_based_loss=False, use_ce_based_loss=True, fg_top_p=0.25, bg_top_p=0.4, fg_weight=1.5, bg_weight=0.5, com_loss_scale=0.03),
+    "smooth": dict(smooth_attn=True, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0),
+    "renorm": dict(attn_renorm=True, num_tokens=9, renorm_scale=2.0, fg_top_p=0.5, bg_top_p=0.5, fg_weight=1.0, bg_weight=2.0, com_loss_scale=0.03),
+    "smooth_renorm": dict(smooth_attn=True, attn_renorm=True, num_tokens=8, renorm_scale=3.0, fg_top_p=0.3, bg_top_p=0.4, fg_weight=1.5, bg_weight=1.0,
+                          boxdiff_loss_scale=0.4),
 }
 
 
