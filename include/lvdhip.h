@@ -315,6 +315,10 @@ typedef struct {
   int32_t samples_per_key;
   float scale;
   float* probs;                         /* out [samples, heads, P, ntext] fp32 */
+  const float* key_bias;                /* optional [samples, ld_key_bias]: additive score bias per (sample, text position) — the (batch, 1, T)
+                                           attention_mask Transformer2DModel builds from encoder_attention_mask (models/transformer_2d.py:303-307:
+                                           (1 - mask) * -10000) and AttnProcessor adds in get_attention_scores (:222-258); NULL = none */
+  int32_t ld_key_bias;
 } lvd_ca_probs_full_params;
 int lvdhip_ca_probs_full(const lvd_ca_probs_full_params* p, void* stream);
 

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void ca_probs_full_kernel(const lvd_ca_probs_f
   __syncthreads();
   if (!live) return;
   const float sc = p.scale * 1.4426950408889634f;
+  const float* kbias = p.key_bias ? p.key_bias + (long)s * p.ld_key_bias : nullptr;  // wave-uniform
   float v[3][16], m = -1e30f;
 #pragma unroll
   for (int kt = 0; kt < 3; ++kt) {
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(256) void ca_probs_full_kernel(const lvd_ca_probs_f
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int kidx = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      v[kt][e] = kidx < p.ntext ? st[e] * sc : -1e30f;
+      float sv = st[e] * sc;
+      if (kbias) sv += kbias[min(kidx, p.ntext - 1)] * 1.4426950408889634f;
+      v[kt][e] = kidx < p.ntext ? sv : -1e30f;
       m = fmaxf(m, v[kt][e]);
     }
   }

@@ -61,7 +61,7 @@ def _topk_count(n, p):
     return max(1, int(np.float32(n) * np.float32(p)))
 
 
-def ca_probability_maps(q, k, *, samples, heads, positions, ntext, samples_per_key=1, scale=0.125):
+def ca_probability_maps(q, k, *, samples, heads, positions, ntext, samples_per_key=1, scale=0.125, key_bias=None):
     """softmax(scale * Q K^T) over all text positions as the reference's slow path materialises and saves it
     (models/attention_processor.py:515-552 -> :553-586): q [samples*positions, heads*64] bf16, k [(samples / samples_per_key) * ntext,
     heads*64] bf16 -> (samples, heads, positions, ntext) fp32, one launch of `lvdhip_ca_probs_full`."""
@@ -73,6 +73,10 @@ def ca_probability_maps(q, k, *, samples, heads, positions, ntext, samples_per_k
     probs = torch.empty((samples, heads, positions, ntext), dtype=torch.float32, device=q.device)
     a = hip.CaProbsFullParams(q=q.data_ptr(), ldq=q.stride(0), k=k.data_ptr(), ldk=k.stride(0), samples=samples, heads=heads, P=positions,
                               ntext=ntext, samples_per_key=samples_per_key, scale=float(scale), probs=probs.data_ptr())
+    if key_bias is not None:  # (samples, ntext) fp32 additive score bias per text position: the cross-attention attention_mask
+        if key_bias.dtype != torch.float32 or tuple(key_bias.shape) != (samples, ntext) or key_bias.stride(1) != 1 or key_bias.device != q.device:
+            raise ValueError(f"ca_probability_maps: key_bias must be fp32 ({samples}, {ntext}) on the queries' device, got {tuple(key_bias.shape)} {key_bias.dtype}")
+        a.key_bias, a.ld_key_bias = key_bias.data_ptr(), key_bias.stride(0)
     ops.use_device(q.device)
     hip.check(hip.lib().lvdhip_ca_probs_full(C.byref(a), torch.cuda.current_stream().cuda_stream), "ca_probs_full")
     return probs

@@ -119,7 +119,7 @@ class CaProbsFullParams(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("ldq", i32), ("k", C.c_void_p), ("ldk", i32),
         ("samples", i32), ("heads", i32), ("P", i32), ("ntext", i32), ("samples_per_key", i32), ("scale", f32),
-        ("probs", C.c_void_p),
+        ("probs", C.c_void_p), ("key_bias", C.c_void_p), ("ld_key_bias", i32),
     ]
 
 
@@ -213,7 +213,7 @@ SYMBOLS = {
 _lib = None
 # The ctypes structs above mirror include/lvdhip.h at exactly this lvdhip_version(): a stale liblvdhip.so would silently ignore fields
 # added since (ldrowbias, acc_mode, ...) and compute something else, so lib() refuses any other version.
-ABI_VERSION = 107
+ABI_VERSION = 108
 CA_MAX_KEYS = 8  # LVD_CA_MAX_KEYS
 
 

@@ -7,8 +7,9 @@ encoder states (B, T, D) it returns the attended hidden states; when the key is 
 (B, heads, L, T) are stored in `save_attn_to_dict[tuple(attn_key)]`; an `attn_process_fn` rewrites the cross-attention
 probabilities before they meet V (:537-549).  Every branch runs on the C ABI: the fused attention (`lvdhip_attention_fwd`), the
 materialised map of the slow path (`lvdhip_ca_probs_full`) and the product of processed probabilities with V
-(`lvdhip_ca_apply_probs`).  Constraints of the kernels: CUDA tensors, head dim 64, no attention mask (the reference never
-passes one on this path, unet_3d_blocks.py:406 TODO)."""
+(`lvdhip_ca_apply_probs`).  Constraints of the kernels: CUDA tensors, head dim 64; `attention_mask` only as the per-text-position
+additive bias of cross-attention (what Transformer2DModel builds from `encoder_attention_mask`; the reference never passes one on
+this path, unet_3d_blocks.py:406 TODO) — any other mask raises."""
 import torch
 
 from .. import ops
@@ -29,8 +30,17 @@ class HipAttnProcessor:
                  attn_key=None, attn_process_fn=None, return_cond_ca_only=False, return_token_ca_only=None,
                  offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None, enable_flash_attn=True,
                  cross_attn_save_hidden_states=False):
+        key_bias = None
         if attention_mask is not None:
-            raise NotImplementedError("attention_mask is not supported by the HIP attention kernels (the reference passes none on this path)")
+            # the additive bias Transformer2DModel derives from encoder_attention_mask ((1 - mask) * -10000, one singleton query dimension:
+            # models/transformer_2d.py:303-307) and get_attention_scores adds to the scores (:222-258): one value per (sample, text position).
+            # Cross-attention only; a bias that varies over the queries or the heads, or any self-attention mask, has no kernel here.
+            m = attention_mask
+            if encoder_hidden_states is None or not torch.is_floating_point(m) or m.shape[-1] != encoder_hidden_states.shape[1] \
+                    or m.dim() not in (2, 3) or (m.dim() == 3 and m.shape[1] != 1) or m.shape[0] != hidden_states.shape[0]:
+                raise NotImplementedError("attention_mask: only a floating-point additive bias of shape (batch, text) or (batch, 1, text) on cross-attention is "
+                                          f"supported by the HIP kernels (got {tuple(m.shape)} {m.dtype}, cross-attention: {encoder_hidden_states is not None})")
+            key_bias = m.reshape(m.shape[0], m.shape[-1]).to(torch.float32).contiguous()
         if hidden_states.dim() != 3 or not hidden_states.is_cuda:
             raise ValueError("HipAttnProcessor expects CUDA hidden states of shape (batch, tokens, channels)")
         B, L, Cc = hidden_states.shape
@@ -51,16 +61,18 @@ class HipAttnProcessor:
             self.hidden_states = hidden_states  # models/attention_processor.py:456-457
         want = return_attntion_probs or (save_attn_to_dict is not None and (save_keys is None or tuple(attn_key) in save_keys))
         probs = None
-        if cross and (want or attn_process_fn is not None):
-            # probabilities are only materialised on request (visualisation / external losses / a caller's rewrite); fp32 like the loss maths
+        if cross and (want or attn_process_fn is not None or key_bias is not None):
+            # probabilities are only materialised on request (visualisation / external losses / a caller's rewrite / a masked prompt); fp32 like the loss maths
             from ..guidance import ca_apply_probabilities, ca_probability_maps
-            probs = ca_probability_maps(q, k, samples=B, heads=heads, positions=L, ntext=T, scale=scale)
+            probs = ca_probability_maps(q, k, samples=B, heads=heads, positions=L, ntext=T, scale=scale, key_bias=key_bias)
         if cross and attn_process_fn is not None:
             # :537-549 — the callback sees (batch*heads, L, T) probabilities and head-batched q / k / v, and returns what meets V
             hb = lambda t, n: t.reshape(B, n, heads, 64).permute(0, 2, 1, 3).reshape(B * heads, n, 64)
             processed = attn_process_fn(probs.reshape(B * heads, L, T).clone(), hb(q, L), hb(k, T), hb(v, T), attn_key=attn_key, cross_attn=cross,
                                         batch_size=B, heads=heads)
             o = ca_apply_probabilities(processed, v, samples=B, heads=heads, positions=L, ntext=T)
+        elif key_bias is not None:  # masked cross-attention: the biased map times V (the fused kernel takes no bias)
+            o = ca_apply_probabilities(probs, v, samples=B, heads=heads, positions=L, ntext=T)
         else:
             o = torch.empty_like(q)
             ops.attention_fwd(q, k, v, o, samples=B, heads=heads, sq=L, skv=T, qmap=ops.RowMap(1, L, 0, 1), kvmap=ops.RowMap(1, T, 0, 1), scale=scale)

@@ -63,8 +63,23 @@ def test_attn_processor_plugin():
     assert rel(out, ref) < 2e-2 and rel(saved[("down", 1, 0, 0)], probs) < 2e-2
     out_self = proc(_Attn(128, 128, 2).cuda(), x, attn_key=["in", 0, 0])
     assert out_self.shape == x.shape and torch.isfinite(out_self).all()
+    # attention_mask on cross-attention: the additive per-text-position bias of models/transformer_2d.py:303-307 ((1 - mask) * -10000, (batch, 1, text))
+    keep = torch.ones(3, 77, device="cuda")
+    keep[0, 40:] = 0
+    keep[2, 9:] = 0
+    bias = ((1 - keep) * -10000.0).unsqueeze(1)
+    sm = {}
+    om = proc(attn, x, encoder_hidden_states=ctx, attention_mask=bias, attn_key=["down", 1, 0, 0], save_attn_to_dict=sm, save_keys=[("down", 1, 0, 0)])
+    pm = (sp(q) @ sp(k).transpose(-1, -2) * 0.125 + bias[:, None]).softmax(-1)
+    refm = attn.to_out[0]((pm @ sp(v)).permute(0, 2, 1, 3).reshape(3, 50, 128))
+    assert rel(om, refm) < 2e-2 and rel(sm[("down", 1, 0, 0)], pm) < 2e-2 and float(sm[("down", 1, 0, 0)][0, :, :, 40:].abs().max()) == 0.0
+    assert rel(proc(attn, x, encoder_hidden_states=ctx, attention_mask=bias[:, 0]), refm) < 2e-2  # (batch, text) spelling
+    with pytest.raises(NotImplementedError):  # a mask over the queries, a boolean mask, or a self-attention mask: no kernel
+        proc(attn, x, encoder_hidden_states=ctx, attention_mask=torch.zeros(3, 50, 77, device="cuda"))
     with pytest.raises(NotImplementedError):
-        proc(attn, x, encoder_hidden_states=ctx, attention_mask=torch.ones(3, 77, device="cuda"))
+        proc(attn, x, encoder_hidden_states=ctx, attention_mask=keep.bool())
+    with pytest.raises(NotImplementedError):
+        proc(_Attn(128, 128, 2).cuda(), x, attention_mask=torch.zeros(3, 1, 50, device="cuda"))
     # slicing / pairing options of the saved map (models/attention_processor.py:566-583)
     o2, p2 = proc(attn, x[:2], encoder_hidden_states=ctx[:2], attn_key=["up", 1, 0, 0], return_attntion_probs=True, return_token_ca_only=5,
                   return_cond_ca_only=True, offload_cross_attn_to_cpu=True)
